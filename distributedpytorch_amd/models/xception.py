@@ -1,0 +1,127 @@
+"""Aligned Xception-65 backbone (DeepLabv3+), ``BASELINE.json`` config 5 (output-stride 8,
+"heavy atrous conv").
+
+Every separable unit is ``depthwise 3×3 (atrous) → BN → pointwise 1×1 → BN``: the depthwise part
+runs the memory-bound K13 kernel, the pointwise part the MFMA implicit-GEMM kernel (SURVEY.md
+§2.5).  Activations between units are fused into the preceding BN (``relu=True``) wherever the
+pre-activation structure allows it.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from ..ops import BatchNorm2d, Conv2d
+
+
+class SeparableConv2d(nn.Module):
+    """'same'-padded depthwise (dilated) conv + BN + pointwise conv."""
+
+    def __init__(self, cin: int, cout: int, stride: int = 1, dilation: int = 1):
+        super().__init__()
+        # effective kernel 3 + 2·(d-1); symmetric pad = d keeps 'same' for odd maps (513-derived)
+        self.conv1 = Conv2d(cin, cin, 3, stride=stride, padding=dilation, dilation=dilation,
+                            groups=cin, bias=False)
+        self.bn = BatchNorm2d(cin)
+        self.pointwise = Conv2d(cin, cout, 1, bias=False)
+
+    def forward(self, x):
+        return self.pointwise(self.bn(self.conv1(x)))
+
+
+class _Unit(nn.Module):
+    """separable conv + BN (+ fused ReLU feeding the next unit)."""
+
+    def __init__(self, cin, cout, stride, dilation, relu_after):
+        super().__init__()
+        self.sep = SeparableConv2d(cin, cout, stride, dilation)
+        self.bn = BatchNorm2d(cout)
+        self.relu_after = relu_after
+
+    def forward(self, x):
+        return self.bn(self.sep(x), relu=self.relu_after)
+
+
+class XceptionBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, reps: int, stride: int = 1, dilation: int = 1,
+                 start_with_relu: bool = True, grow_first: bool = True, is_last: bool = False):
+        super().__init__()
+        self.start_with_relu = start_with_relu
+        if cout != cin or stride != 1:
+            self.skip = Conv2d(cin, cout, 1, stride=stride, bias=False)
+            self.skipbn = BatchNorm2d(cout)
+        else:
+            self.skip = None
+        plan = []  # (cin, cout, stride, dilation)
+        c = cin
+        if grow_first:
+            plan.append((c, cout, 1, dilation))
+            c = cout
+        for _ in range(reps - 1):
+            plan.append((c, c, 1, dilation))
+        if not grow_first:
+            plan.append((c, cout, 1, dilation))
+        if stride != 1:
+            plan.append((cout, cout, stride, 1))
+        elif is_last:
+            plan.append((cout, cout, 1, dilation))
+        units = []
+        for i, (a, b, s, d) in enumerate(plan):
+            units.append(_Unit(a, b, s, d, relu_after=(i + 1 < len(plan))))
+        self.rep = nn.Sequential(*units)
+
+    def forward(self, inp):
+        x = torch.relu(inp) if self.start_with_relu else inp
+        # pre-activation quirk of the published weights: the shortcut sees the activated input
+        short = x
+        x = self.rep(x)
+        if self.skip is not None:
+            return self.skipbn(self.skip(short), residual=x)
+        return x + short
+
+
+class AlignedXception(nn.Module):
+    """Returns ``(features[2048], low_level[128 @ stride 4])``."""
+
+    def __init__(self, output_stride: int = 16, in_channels: int = 3):
+        super().__init__()
+        if output_stride == 16:
+            entry3_stride, mid_dil, exit_dil = 2, 1, (1, 2)
+        elif output_stride == 8:
+            entry3_stride, mid_dil, exit_dil = 1, 2, (2, 4)
+        else:
+            raise ValueError("output_stride must be 8 or 16")
+        self.conv1 = Conv2d(in_channels, 32, 3, stride=2, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(32)
+        self.conv2 = Conv2d(32, 64, 3, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(64)
+        self.block1 = XceptionBlock(64, 128, 2, stride=2, start_with_relu=False)
+        self.block2 = XceptionBlock(128, 256, 2, stride=2, start_with_relu=False)
+        self.block3 = XceptionBlock(256, 728, 2, stride=entry3_stride, is_last=True)
+        self.middle = nn.Sequential(*[XceptionBlock(728, 728, 3, dilation=mid_dil) for _ in range(16)])
+        self.block20 = XceptionBlock(728, 1024, 2, dilation=exit_dil[0], grow_first=False, is_last=True)
+        self.conv3 = SeparableConv2d(1024, 1536, dilation=exit_dil[1])
+        self.bn3 = BatchNorm2d(1536)
+        self.conv4 = SeparableConv2d(1536, 1536, dilation=exit_dil[1])
+        self.bn4 = BatchNorm2d(1536)
+        self.conv5 = SeparableConv2d(1536, 2048, dilation=exit_dil[1])
+        self.bn5 = BatchNorm2d(2048)
+        self.out_channels, self.low_level_channels = 2048, 128
+        self.output_stride = output_stride
+
+    def forward(self, x):
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
+        x = self.block1(x)
+        low = torch.relu(x)
+        x = self.block2(low)
+        x = self.block3(x)
+        x = self.middle(x)
+        x = self.block20(x)
+        x = torch.relu(x)
+        x = self.bn3(self.conv3(x), relu=True)
+        x = self.bn4(self.conv4(x), relu=True)
+        x = self.bn5(self.conv5(x), relu=True)
+        return x, low

@@ -1,0 +1,107 @@
+"""Loader for the in-tree HIP kernel library (``csrc/libdpamd_hip.so``) and backend policy.
+
+Policy
+------
+* CUDA(=HIP) tensors run the hand-written gfx950 kernels.  If the shared object is missing on a
+  GPU box the first kernel call raises — there is no silent eager fallback.
+* CPU tensors (the gloo plumbing configuration, ``BASELINE.json`` config 1) run a plain PyTorch
+  implementation of the same math; that implementation is also the fp32 reference the numerics
+  tests compare the kernels against.
+* ``set_backend('torch')`` forces the PyTorch implementation everywhere.  It exists for exactly two
+  things: measuring the stock MIOpen baseline (``bench.py --impl stock``) and
+  reference values in tests.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdpamd_hip.so")
+HOST_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdpamd_host.so")
+
+_lock = threading.Lock()
+_lib = None
+_host_lib = None
+_mode = os.environ.get("DPAMD_BACKEND", "auto")  # 'auto' | 'torch'
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def set_backend(mode: str) -> None:
+    global _mode
+    if mode not in ("auto", "torch"):
+        raise ValueError("backend must be 'auto' or 'torch'")
+    _mode = mode
+
+
+def get_backend() -> str:
+    return _mode
+
+
+class backend:
+    """Context manager: ``with backend('torch'): ...``"""
+
+    def __init__(self, mode: str):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_backend()
+        set_backend(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_backend(self.prev)
+        return False
+
+
+def use_hip(t: torch.Tensor) -> bool:
+    """True when tensor ``t`` must be processed by the HIP kernels."""
+    return t.is_cuda and _mode != "torch"
+
+
+def lib() -> ctypes.CDLL:
+    """The device-kernel library.  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.isfile(LIB_PATH):
+                    raise NativeLibraryMissing(
+                        f"{LIB_PATH} not found: run `python -m distributedpytorch_amd.csrc.build` "
+                        "(hipcc --offload-arch=gfx950) before using the GPU path")
+                _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def host_lib() -> ctypes.CDLL | None:
+    """The host-side C++ runtime (CPU image warps, bucket planner).  Optional on CPU."""
+    global _host_lib
+    if _host_lib is None and os.path.isfile(HOST_LIB_PATH):
+        with _lock:
+            if _host_lib is None:
+                _host_lib = ctypes.CDLL(HOST_LIB_PATH)
+    return _host_lib
+
+
+def lib_built() -> bool:
+    return os.path.isfile(LIB_PATH)
+
+
+def stream_ptr() -> ctypes.c_void_p:
+    """Current HIP stream as a raw ``hipStream_t`` for the C launchers."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"HIP launcher '{what}' failed with status {status}")

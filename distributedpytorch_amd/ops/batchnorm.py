@@ -1,0 +1,248 @@
+"""Fused BatchNorm (+residual) (+ReLU) with optional cross-rank statistics synchronisation.
+
+SURVEY.md §2.5 K4/K5 (fused BN-stats, BN-apply+ReLU, fused BN+ReLU backward) and §2.6 C4
+(SyncBatchNorm all-reduce of ``[Σx, Σx², count]`` forward and ``[Σdy, Σdy·x̂]`` backward).  The
+reference only names the knob (``sync_bn=False, freeze_bn=True`` in the commented DeepLab ctor,
+`/root/reference/train_pascal.py:85`); semantics follow ``torch.nn.BatchNorm2d``/``SyncBatchNorm``.
+
+One ``autograd.Function`` orchestrates four primitives; each primitive is a HIP kernel on GPU and
+plain tensor math on CPU, so the gloo plumbing test exercises exactly the same collective
+schedule as the RCCL run:
+
+    stats      x            -> Σx, Σx²                       (per channel, fp32)
+    apply      x,scale,shift[,residual] -> y = act(x·scale+shift (+residual))
+    bwd_reduce dy,x|y       -> Σdy', Σdy'·x̂                  (dy' = dy masked by the ReLU)
+    bwd_apply  dy,x|y,...   -> dx (, d_residual)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _backend as B
+
+
+# --------------------------------------------------------------------------------------
+# primitives (torch math = CPU path and numerical reference)
+# --------------------------------------------------------------------------------------
+def _t_stats(x: torch.Tensor):
+    xf = x.float()
+    return xf.sum(dim=(0, 2, 3)), (xf * xf).sum(dim=(0, 2, 3))
+
+
+def _t_apply(x, scale, shift, residual, relu):
+    y = x.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual.float()
+    if relu:
+        y = torch.relu(y)
+    return y.to(x.dtype)
+
+
+def _t_bwd_reduce(dy, x, y, mean, invstd, relu):
+    dyf = dy.float()
+    if relu:
+        dyf = dyf * (y > 0)
+    xhat = (x.float() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    return dyf.sum(dim=(0, 2, 3)), (dyf * xhat).sum(dim=(0, 2, 3))
+
+
+def _t_bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres):
+    dyf = dy.float()
+    if relu:
+        dyf = dyf * (y > 0)
+    v = lambda t: t.view(1, -1, 1, 1)  # noqa: E731
+    xhat = (x.float() - v(mean)) * v(invstd)
+    dx = v(weight * invstd) * (dyf - v(sum_dy) / count - xhat * v(sum_dy_xhat) / count)
+    dres = dyf.to(dy.dtype) if need_dres else None
+    return dx.to(x.dtype), dres
+
+
+def _stats(x):
+    if B.use_hip(x):
+        from . import _hip_bn
+        return _hip_bn.stats(x)
+    return _t_stats(x)
+
+
+def _apply(x, scale, shift, residual, relu):
+    if B.use_hip(x):
+        from . import _hip_bn
+        return _hip_bn.apply(x, scale, shift, residual, relu)
+    return _t_apply(x, scale, shift, residual, relu)
+
+
+def _bwd_reduce(dy, x, y, mean, invstd, relu):
+    if B.use_hip(x):
+        from . import _hip_bn
+        return _hip_bn.bwd_reduce(dy, x, y, mean, invstd, relu)
+    return _t_bwd_reduce(dy, x, y, mean, invstd, relu)
+
+
+def _bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres):
+    if B.use_hip(x):
+        from . import _hip_bn
+        return _hip_bn.bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres)
+    return _t_bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres)
+
+
+def _group_active(group) -> bool:
+    return (group is not False and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size(group if group is not True else None) > 1)
+
+
+# --------------------------------------------------------------------------------------
+# training-mode function
+# --------------------------------------------------------------------------------------
+class _BatchNormActTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group):
+        C = x.shape[1]
+        local_count = x.numel() // C
+        s, ss = _stats(x)
+        count = float(local_count)
+        sync = _group_active(group)
+        pg = None if group is True else group
+        if sync:
+            # C4: one fused message [Σx | Σx² | count] per layer (2C+1 floats).
+            packed = torch.cat([s, ss, s.new_tensor([count])])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
+            s, ss = packed[:C], packed[C:2 * C]
+            if x.is_cuda:
+                # no device->host sync on the hot path: the sampler drops the ragged tail, so every
+                # rank contributes the same B·H·W (checked under DPAMD_DEBUG in parallel.debug)
+                count = float(local_count * dist.get_world_size(pg))
+            else:
+                count = float(packed[2 * C].item())
+        mean = s / count
+        var = (ss / count - mean * mean).clamp_min_(0.0)
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                unbiased = var * (count / max(count - 1.0, 1.0))
+                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        w = weight.float() if weight is not None else torch.ones_like(mean)
+        b = bias.float() if bias is not None else torch.zeros_like(mean)
+        scale = w * invstd
+        shift = b - mean * scale
+        y = _apply(x, scale, shift, residual, relu)
+        ctx.save_for_backward(x, y if relu else None, w, mean, invstd)
+        ctx.relu, ctx.count, ctx.sync, ctx.pg = relu, count, sync, pg
+        ctx.has_res = residual is not None
+        ctx.has_affine = weight is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w, mean, invstd = ctx.saved_tensors
+        if not dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        C = x.shape[1]
+        sdy, sdyx = _bwd_reduce(dy, x, y, mean, invstd, ctx.relu)
+        g_sdy, g_sdyx = sdy, sdyx
+        if ctx.sync:
+            packed = torch.cat([sdy, sdyx])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.pg)
+            g_sdy, g_sdyx = packed[:C], packed[C:]
+        need_dres = ctx.has_res and ctx.needs_input_grad[3]
+        dx, dres = _bwd_apply(dy, x, y, mean, invstd, w, g_sdy, g_sdyx, ctx.count, ctx.relu, need_dres)
+        # affine grads are *local* sums: DDP's gradient all-reduce averages them like any other param
+        dweight = sdyx.to(w.dtype) if ctx.has_affine else None
+        dbias = sdy.to(w.dtype) if ctx.has_affine else None
+        return dx, dweight, dbias, dres, None, None, None, None, None, None
+
+
+class _BatchNormActFrozen(torch.autograd.Function):
+    """Eval-statistics BN (``freeze_bn``) fused with residual/ReLU; differentiable w.r.t. x."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        y = _apply(x, scale, shift, residual, relu)
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        dyf = dy.float()
+        if ctx.relu:
+            dyf = dyf * (y > 0)
+        dx = (dyf * scale.view(1, -1, 1, 1)).to(dy.dtype)
+        dres = dyf.to(dy.dtype) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, None, None, dres, None
+
+
+def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, training: bool,
+                   momentum: float = 0.1, eps: float = 1e-5, relu: bool = False,
+                   residual: Optional[torch.Tensor] = None, group=False) -> torch.Tensor:
+    """``act(BN(x) + residual)``.  ``group``: ``False`` = local statistics, ``True`` = default
+    process group, or a ``ProcessGroup`` = statistics all-reduced over that group."""
+    if B.get_backend() == "torch" and not _group_active(group):
+        # stock baseline: MIOpen / ATen batch-norm followed by separate add and ReLU
+        y = F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    if training:
+        return _BatchNormActTrain.apply(x, weight, bias, residual, running_mean, running_var,
+                                        momentum, eps, relu, group)
+    invstd = torch.rsqrt(running_var.float() + eps)
+    scale = invstd * (weight.float() if weight is not None else 1.0)
+    shift = (bias.float() if bias is not None else 0.0) - running_mean.float() * scale
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _BatchNormActFrozen.apply(x, scale, shift, residual, relu)
+    return _apply(x, scale, shift, residual, relu)
+
+
+class BatchNorm2d(nn.Module):
+    """``nn.BatchNorm2d``-compatible parameters/buffers; forward takes fusion flags.
+
+    ``forward(x, relu=False, residual=None)`` computes ``act(BN(x) + residual)`` in one kernel pass.
+    ``sync`` turns on cross-rank statistics (SyncBatchNorm); ``frozen`` uses running statistics
+    even in training mode (the reference's ``freeze_bn``)."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1,
+                 sync: bool = False, frozen: bool = False, process_group=None):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.sync, self.frozen, self.process_group = sync, frozen, process_group
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None):
+        training = self.training and not self.frozen
+        group = False
+        if self.sync and training:
+            group = self.process_group if self.process_group is not None else True
+        return batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                              training, self.momentum, self.eps, relu, residual, group)
+
+    def extra_repr(self) -> str:
+        return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "
+                f"sync={self.sync}, frozen={self.frozen}")
+
+
+def convert_sync_batchnorm(module: nn.Module, process_group=None) -> nn.Module:
+    """Turn on cross-rank statistics for every ``BatchNorm2d`` in ``module`` (in place)."""
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d):
+            m.sync, m.process_group = True, process_group
+    return module
+
+
+def freeze_batchnorm(module: nn.Module) -> nn.Module:
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d):
+            m.frozen = True
+            m.weight.requires_grad_(False)
+            m.bias.requires_grad_(False)
+    return module

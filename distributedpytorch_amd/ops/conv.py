@@ -1,0 +1,112 @@
+"""Convolution: implicit-GEMM (dilated) conv on MFMA for gfx950, plus depthwise conv.
+
+SURVEY.md §2.5 K1/K2/K3 (dense conv fwd / dgrad / wgrad) and K13 (depthwise atrous conv for the
+Xception backbone).  The reference only ever reaches a convolution through its external model
+(`/root/reference/train_pascal.py:86`, `:195`, `:216`); the kernels here are what that call lowers
+to on MI355X.
+
+Layout contract of the GPU path: activations are ``[N, C, H, W]``-shaped tensors stored
+channels-last (NHWC in memory), bf16; weights are ``[Cout, Cin/g, kh, kw]`` fp32 master parameters
+(state_dict compatible) with a cached bf16 channels-last copy (KRSC in memory) consumed by the
+kernels.  Gradients w.r.t. weights are produced in fp32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _backend as B
+
+_IntOr2 = Union[int, Tuple[int, int]]
+
+
+def _pair(v: _IntOr2) -> Tuple[int, int]:
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def conv_out_size(n: int, k: int, s: int, p: int, d: int) -> int:
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+# --------------------------------------------------------------------------------------
+# functional entry
+# --------------------------------------------------------------------------------------
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           stride: _IntOr2 = 1, padding: _IntOr2 = 0, dilation: _IntOr2 = 1, groups: int = 1,
+           w_lowp: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """2-D convolution.  ``w_lowp`` is an optional up-to-date bf16 KRSC copy of ``weight``."""
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if B.use_hip(x):
+        from . import _hip_conv
+        return _hip_conv.conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    b = None if bias is None else bias.to(x.dtype)
+    return F.conv2d(x, w, b, stride, padding, dilation, groups)
+
+
+class Conv2d(nn.Module):
+    """Drop-in ``nn.Conv2d`` (same parameter names/shapes) running the HIP kernels on GPU."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: _IntOr2, stride: _IntOr2 = 1,
+                 padding: _IntOr2 = 0, dilation: _IntOr2 = 1, groups: int = 1, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups = groups
+        kh, kw = self.kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, kh, kw))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._lowp: Optional[torch.Tensor] = None
+        self._lowp_version = -1
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+        if self.bias is not None:
+            fan_in = self.weight[0].numel()
+            bound = 1.0 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def lowp_weight(self, dtype: torch.dtype) -> torch.Tensor:
+        """bf16 KRSC copy of the master weight, refreshed when the parameter changes.
+
+        The fused SGD kernel (ops.sgd) writes this copy in the same pass as the fp32 update and
+        bumps ``_lowp_version`` so no separate cast kernel runs in steady state."""
+        w = self.weight
+        arena_copy = getattr(w, "_dpamd_lowp", None)
+        if arena_copy is not None and arena_copy.dtype == dtype:
+            # parallel.arena keeps this view fresh (the fused SGD kernel writes it); only an
+            # out-of-band in-place edit of the master weight (init, load_state_dict) needs a re-cast
+            if getattr(w, "_dpamd_lowp_version", -1) != w._version:
+                with torch.no_grad():
+                    arena_copy.copy_(w.detach())
+                w._dpamd_lowp_version = w._version
+            return arena_copy
+        if (self._lowp is None or self._lowp_version != w._version or self._lowp.dtype != dtype
+                or self._lowp.device != w.device):
+            with torch.no_grad():
+                self._lowp = w.detach().to(dtype).contiguous(memory_format=torch.channels_last)
+            self._lowp_version = w._version
+        return self._lowp
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        w_lowp = self.lowp_weight(x.dtype) if (B.use_hip(x) and x.dtype != self.weight.dtype) else None
+        return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                      self.groups, w_lowp)
+
+    def extra_repr(self) -> str:
+        s = f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}"
+        if self.padding != (0, 0):
+            s += f", padding={self.padding}"
+        if self.dilation != (1, 1):
+            s += f", dilation={self.dilation}"
+        if self.groups != 1:
+            s += f", groups={self.groups}"
+        if self.bias is None:
+            s += ", bias=False"
+        return s

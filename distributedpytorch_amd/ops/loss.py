@@ -1,0 +1,50 @@
+"""Ignore-index softmax cross-entropy, SURVEY.md §2.5 K7.
+
+The reference computes its loss with ``criterion.forward(output, gts)``
+(`/root/reference/train_pascal.py:199`); the north star replaces the binary loss by a 21-class
+softmax CE with the VOC void label 255 ignored.  GPU path: ONE kernel pass computes the per-pixel
+loss, the valid-pixel count and ``dlogits``; backward only scales the stored ``dlogits``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _backend as B
+
+
+class _SoftmaxCEHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        from . import _hip_misc
+        loss, dlogits = _hip_misc.softmax_ce_fwd(logits, target, ignore_index, logits.requires_grad)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dlogits,) = ctx.saved_tensors
+        from . import _hip_misc
+        return _hip_misc.scale_(dlogits, gloss), None, None
+
+
+def softmax_cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = 255) -> torch.Tensor:
+    """Mean CE over non-ignored pixels.  ``logits`` [N,C,H,W], ``target`` [N,H,W] integer."""
+    if B.use_hip(logits):
+        return _SoftmaxCEHip.apply(logits, target, ignore_index)
+    return F.cross_entropy(logits.float(), target.long(), ignore_index=ignore_index)
+
+
+class SoftmaxCrossEntropy(nn.Module):
+    def __init__(self, ignore_index: int = 255):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, target):
+        if isinstance(logits, (tuple, list)):  # auxiliary heads: main + 0.4·aux (FCN convention)
+            main = softmax_cross_entropy(logits[0], target, self.ignore_index)
+            for aux in logits[1:]:
+                main = main + 0.4 * softmax_cross_entropy(aux, target, self.ignore_index)
+            return main
+        return softmax_cross_entropy(logits, target, self.ignore_index)

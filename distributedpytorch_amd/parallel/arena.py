@@ -1,0 +1,152 @@
+"""Flat parameter / gradient / momentum arenas.
+
+All trainable parameters of a model are re-homed into ONE contiguous fp32 buffer (and their
+gradients, momenta and the bf16 compute copies into three more buffers with the *same element
+order*).  Consequences, all of them MI355X-motivated (288 GB HBM: four flat copies of a 59 M
+parameter model are ~0.8 GB, irrelevant):
+
+* gradient buckets for the RCCL all-reduce are plain slices of the gradient arena — no
+  flatten/unflatten copies;
+* the optimiser is one fused kernel launch per contiguous learning-rate segment instead of ~400
+  tiny per-tensor launches;
+* 4-D convolution weights are stored channels-last (KRSC in memory), so the bf16 arena holds
+  exactly the operand layout the implicit-GEMM kernels read, refreshed by the SGD kernel itself.
+
+Arena order is REVERSE registration order: backward produces gradients roughly last-layer-first,
+so bucket 0 fills first and its all-reduce overlaps the remaining backward.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+_ALIGN = 64  # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
+
+
+@dataclass
+class Slot:
+    param: nn.Parameter
+    name: str
+    offset: int
+    numel: int
+    group: int
+    bucket: int = -1
+
+
+@dataclass
+class Bucket:
+    index: int
+    start: int
+    end: int
+    slots: List[int] = field(default_factory=list)
+
+
+def _view_like(flat: torch.Tensor, offset: int, p: torch.Tensor) -> torch.Tensor:
+    seg = flat[offset:offset + p.numel()]
+    if p.dim() == 4:
+        o, i, kh, kw = p.shape
+        return seg.view(o, kh, kw, i).permute(0, 3, 1, 2)  # logical OIHW, memory KRSC
+    return seg.view(p.shape)
+
+
+class ParamArena:
+    def __init__(self, named_param_groups: Sequence[Iterable], bucket_bytes: int = 64 << 20,
+                 lowp_dtype: Optional[torch.dtype] = None):
+        """``named_param_groups``: one iterable of ``(name, Parameter)`` per optimiser group."""
+        entries = []
+        seen = set()
+        for gi, group in enumerate(named_param_groups):
+            for name, p in group:
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    entries.append((name, p, gi))
+        if not entries:
+            raise ValueError("no trainable parameters")
+        self._reg_index = {id(p): k for k, (_, p, _) in enumerate(entries)}
+        device = entries[0][1].device
+        ordered = list(reversed(entries))
+        self.slots: List[Slot] = []
+        off = 0
+        for name, p, gi in ordered:
+            self.slots.append(Slot(p, name, off, p.numel(), gi))
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.device = device
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_lowp = torch.zeros(off, dtype=lowp_dtype, device=device) if lowp_dtype else None
+        self.lowp_views: Dict[int, torch.Tensor] = {}
+        with torch.no_grad():
+            for s in self.slots:
+                view = _view_like(self.flat_p, s.offset, s.param)
+                view.copy_(s.param.data)
+                s.param.data = view
+                s.param.grad = _view_like(self.flat_g, s.offset, s.param)
+                if self.flat_lowp is not None:
+                    lv = _view_like(self.flat_lowp, s.offset, s.param)
+                    self.lowp_views[id(s.param)] = lv
+                    # consumed by ops.Conv2d.lowp_weight: (view, parameter version it mirrors)
+                    s.param._dpamd_lowp = lv
+            if self.flat_lowp is not None:
+                self.flat_lowp.copy_(self.flat_p)
+                for s in self.slots:
+                    s.param._dpamd_lowp_version = s.param._version
+        # ---- buckets: contiguous slot runs of ~bucket_bytes ----
+        self.buckets: List[Bucket] = []
+        cap = max(bucket_bytes // 4, 1)
+        cur = Bucket(0, 0, 0)
+        for si, s in enumerate(self.slots):
+            span_end = s.offset + (s.numel + _ALIGN - 1) // _ALIGN * _ALIGN
+            if cur.slots and span_end - cur.start > cap:
+                self.buckets.append(cur)
+                cur = Bucket(len(self.buckets), s.offset, s.offset)
+            cur.slots.append(si)
+            cur.end = span_end
+            s.bucket = cur.index
+        self.buckets.append(cur)
+        # ---- optimiser segments: maximal runs of equal group ----
+        self.segments: List[tuple] = []  # (start, end, group)
+        st, g = 0, self.slots[0].group
+        for s in self.slots[1:]:
+            if s.group != g:
+                self.segments.append((st, s.offset, g))
+                st, g = s.offset, s.group
+        self.segments.append((st, self.total, g))
+
+    # ------------------------------------------------------------------
+    def bucket_grad(self, b: int) -> torch.Tensor:
+        bk = self.buckets[b]
+        return self.flat_g[bk.start:bk.end]
+
+    def lowp_of(self, p: nn.Parameter) -> Optional[torch.Tensor]:
+        return self.lowp_views.get(id(p))
+
+    def refresh_lowp(self) -> None:
+        if self.flat_lowp is not None:
+            with torch.no_grad():
+                self.flat_lowp.copy_(self.flat_p)
+            for s in self.slots:
+                s.param._dpamd_lowp_version = s.param._version
+
+    def rebind(self) -> None:
+        """Re-attach ``.data``/``.grad`` views (after ``load_state_dict(assign=True)`` or ``.to()``)."""
+        with torch.no_grad():
+            for s in self.slots:
+                view = _view_like(self.flat_p, s.offset, s.param)
+                if s.param.data.data_ptr() != view.data_ptr():
+                    view.copy_(s.param.data)
+                    s.param.data = view
+                s.param.grad = _view_like(self.flat_g, s.offset, s.param)
+        self.refresh_lowp()
+
+    def zero_grad(self) -> None:
+        self.flat_g.zero_()
+
+    def describe(self) -> str:
+        mb = self.total * 4 / 2 ** 20
+        return (f"ParamArena: {len(self.slots)} tensors, {self.total} elems ({mb:.1f} MiB fp32), "
+                f"{len(self.buckets)} buckets, {len(self.segments)} optimiser segments")

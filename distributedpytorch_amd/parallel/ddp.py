@@ -1,0 +1,136 @@
+"""Data parallelism: one process per GPU, bucketed gradient all-reduce overlapped with backward.
+
+Replaces the reference's single-process ``torch.nn.DataParallel(net, device_ids=[0,1,2,3])``
+(`/root/reference/train_pascal.py:92`), whose every step re-broadcasts parameters, scatters the
+batch, gathers outputs on GPU 0 and reduce-adds gradients there (SURVEY.md §2.6 C1–C3), and
+realises the file's TODO header (`:1-8`).  Here:
+
+* C1 parameters are broadcast ONCE at construction (rank 0 → all);
+* C2 each rank loads its own shard (``parallel.sampler.DistributedSampler``);
+* C3 gradients live in the flat arena; a post-accumulate hook per parameter counts its bucket
+  down and, when a bucket is complete, launches ``all_reduce`` on that arena slice with
+  ``async_op=True`` (RCCL runs it on its own stream, so it overlaps the rest of backward).
+  Buckets launch strictly in index order on every rank, so collective order can never diverge.
+  The ``1/world_size`` average is folded into the fused SGD kernel (``grad_scale``).
+
+xGMI note: the mesh is point-to-point, 7 links per GPU, and ring traffic is
+per-link bound, so buckets default to 64 MiB — few, large messages that RCCL can split across all
+links — rather than DDP's NVSwitch-era 25 MiB.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .arena import ParamArena
+
+
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class DistributedDataParallel(nn.Module):
+    """Wraps ``module``; forward is a pass-through, gradient sync happens via arena hooks.
+
+    The wrapped model is reachable as ``.module`` so ``state_dict()`` keys carry the ``module.``
+    prefix — the key space the reference saves and loads (`train_pascal.py:92`, `:103`, `:230`)."""
+
+    def __init__(self, module: nn.Module, param_groups: Optional[Sequence[Iterable]] = None,
+                 bucket_bytes: int = 64 << 20, lowp_dtype: Optional[torch.dtype] = None,
+                 process_group=None, broadcast_buffers: bool = True):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.world_size = _world(process_group)
+        if param_groups is None:
+            param_groups = [list(module.named_parameters())]
+        self.arena = ParamArena(param_groups, bucket_bytes, lowp_dtype)
+        self._pending: List[int] = []
+        self._ready: List[bool] = []
+        self._works: list = []
+        self._next = 0
+        self._sync_enabled = True
+        self.stats = {"buckets_launched": 0, "bytes_reduced": 0}
+        if self.world_size > 1:
+            self._broadcast_initial_state(broadcast_buffers)
+        self._install_hooks()
+        self.reset_buckets()
+
+    # ------------------------------------------------------------------
+    def _broadcast_initial_state(self, broadcast_buffers: bool) -> None:
+        # C1: one broadcast of the whole parameter arena instead of one per step
+        dist.broadcast(self.arena.flat_p, src=0, group=self.process_group)
+        self.arena.refresh_lowp()
+        if broadcast_buffers:
+            for buf in self.module.buffers():
+                dist.broadcast(buf, src=0, group=self.process_group)
+
+    def _install_hooks(self) -> None:
+        for si, slot in enumerate(self.arena.slots):
+            slot.param.register_post_accumulate_grad_hook(self._make_hook(si))
+
+    def _make_hook(self, si: int):
+        bucket = self.arena.slots[si].bucket
+
+        def hook(param):
+            if not self._sync_enabled:
+                return
+            self._pending[bucket] -= 1
+            if self._pending[bucket] == 0:
+                self._ready[bucket] = True
+                self._drain()
+        return hook
+
+    def _drain(self) -> None:
+        while self._next < len(self.arena.buckets) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
+
+    def _launch(self, b: int) -> None:
+        if self.world_size == 1:
+            return
+        g = self.arena.bucket_grad(b)
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        self._works.append(work)
+        self.stats["buckets_launched"] += 1
+        self.stats["bytes_reduced"] += g.numel() * 4
+
+    # ------------------------------------------------------------------
+    def reset_buckets(self) -> None:
+        self._pending = [len(b.slots) for b in self.arena.buckets]
+        self._ready = [False] * len(self.arena.buckets)
+        self._works = []
+        self._next = 0
+
+    def finish_gradient_sync(self) -> float:
+        """Launch whatever did not fire (unused parameters), wait for every bucket, and return the
+        scale that turns the summed gradients into the average."""
+        if self._sync_enabled:
+            for b in range(self._next, len(self.arena.buckets)):
+                self._launch(b)
+            for w in self._works:
+                w.wait()
+        self.reset_buckets()
+        return 1.0 / self.world_size
+
+    class _NoSync:
+        def __init__(self, ddp):
+            self.ddp = ddp
+
+        def __enter__(self):
+            self.ddp._sync_enabled = False
+
+        def __exit__(self, *exc):
+            self.ddp._sync_enabled = True
+            return False
+
+    def no_sync(self):
+        """Gradient accumulation (the reference's ``nAveGrad``, `train_pascal.py:67`): skip the
+        all-reduce on all but the last micro-batch."""
+        return DistributedDataParallel._NoSync(self)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

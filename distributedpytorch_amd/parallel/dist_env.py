@@ -1,0 +1,118 @@
+"""Rendezvous, device binding and rank-0 guards.
+
+Implements the reference's TODO items "# export CUDA_VISIBLE_DEVICES", the explicit rendezvous
+port, and "# save if master process" (`/root/reference/train_pascal.py:4`, `:7-8`): one process
+per GPU, ``RANK``/``LOCAL_RANK``/``WORLD_SIZE``/``MASTER_ADDR``/``MASTER_PORT`` from the
+environment (torchrun contract), backend ``nccl`` (= RCCL on ROCm, over xGMI) on GPU and ``gloo``
+on CPU.  Failure handling: collectives carry a timeout, and a non-finite loss or
+an exception on any rank aborts the whole job instead of dead-locking the others.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DistInfo:
+    rank: int = 0
+    local_rank: int = 0
+    world_size: int = 1
+    backend: str = "none"
+    device: torch.device = torch.device("cpu")
+
+    @property
+    def is_master(self) -> bool:
+        return self.rank == 0
+
+
+def init_distributed(backend: Optional[str] = None, timeout_s: int = 600,
+                     device: Optional[str] = None) -> DistInfo:
+    """Initialise (or re-use) the default process group from torchrun-style environment."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_gpu = torch.cuda.is_available() and device != "cpu"
+    if use_gpu:
+        ngpu = torch.cuda.device_count()
+        dev = torch.device("cuda", local_rank % max(ngpu, 1))
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        # xGMI / dmabuf IPC requirement of this platform (see task environment notes)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kwargs = dict(backend=backend, rank=rank, world_size=world,
+                      timeout=datetime.timedelta(seconds=timeout_s))
+        if backend == "nccl":
+            kwargs["device_id"] = dev
+        dist.init_process_group(**kwargs)
+    return DistInfo(rank, local_rank, world, backend if world > 1 else "none", dev)
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def is_master() -> bool:
+    return get_rank() == 0
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+@contextmanager
+def master_first():
+    """Rank 0 runs the body first (e.g. dataset preprocessing that WRITES a cache file,
+    `/root/reference/pascal.py:189`); the others wait, then run it against the finished cache."""
+    if not is_master():
+        barrier()
+    try:
+        yield
+    finally:
+        if is_master():
+            barrier()
+
+
+def all_reduce_scalar(value: float, op: str = "sum", device: Optional[torch.device] = None) -> float:
+    if get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64,
+                     device=device if device is not None else _default_device())
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+    return float(t.item())
+
+
+def _default_device() -> torch.device:
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def check_finite_or_abort(loss: torch.Tensor, step: int) -> None:
+    """Failure detection: every rank learns whether ANY rank saw a non-finite loss, and all of
+    them raise together (no rank is left waiting in a collective)."""
+    bad = 0.0 if bool(torch.isfinite(loss.detach()).all()) else 1.0
+    if all_reduce_scalar(bad, "max", loss.device if loss.is_cuda else None) > 0:
+        raise FloatingPointError(f"non-finite loss at step {step} on at least one rank")

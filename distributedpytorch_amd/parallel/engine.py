@@ -1,0 +1,124 @@
+"""Training / evaluation engine: the reference's module-level loop
+(`/root/reference/train_pascal.py:180-308`) and its half-written ``train_epoch`` refactor
+(`:311-354`, TODO "# single fn train / # single fn val" `:1-2`) as a reusable object.
+
+One engine = one rank.  ``train_step`` is the hot path of SURVEY.md §3.1 re-designed:
+
+    batch already on device (GPU augmentation, no per-step host asserts, no ``.item()``)
+    forward  (HIP kernels, bf16 NHWC)
+    loss     (fused ignore-index softmax-CE)
+    backward (bucket all-reduces launch from hooks and overlap the remaining kernels)
+    finish   (wait buckets) → fused SGD (1/world scale, bf16 refresh, grad zero)
+
+The loss is returned as a device tensor; callers decide when to pay for a host read.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from ..ops import confusion_matrix, miou_from_confusion
+from ..utils.timers import PhaseTimer
+from . import dist_env
+from .ddp import DistributedDataParallel
+from .optim import FlatSGD
+
+
+def named_lr_groups(model: nn.Module, head_lr_mult: float = 1.0):
+    """Split parameters into the reference's 1×/10× groups (`train_pascal.py:90-91`)."""
+    if head_lr_mult == 1.0 or not hasattr(model, "get_10x_lr_params"):
+        return [list(model.named_parameters())], [1.0]
+    head_ids = {id(p) for p in model.get_10x_lr_params()}
+    base = [(n, p) for n, p in model.named_parameters() if id(p) not in head_ids]
+    head = [(n, p) for n, p in model.named_parameters() if id(p) in head_ids]
+    return [base, head], [1.0, head_lr_mult]
+
+
+class TrainEngine:
+    def __init__(self, model: nn.Module, criterion: Callable, lr: float = 0.007, momentum: float = 0.9,
+                 weight_decay: float = 5e-4, head_lr_mult: float = 1.0,
+                 device: Optional[torch.device] = None, compute_dtype: Optional[torch.dtype] = None,
+                 bucket_mb: int = 64, accum_steps: int = 1, process_group=None, markers: bool = False):
+        self.device = device or torch.device("cpu")
+        self.on_gpu = self.device.type == "cuda"
+        self.compute_dtype = compute_dtype or (torch.bfloat16 if self.on_gpu else torch.float32)
+        model = model.to(self.device)
+        if self.on_gpu:
+            model = model.to(memory_format=torch.channels_last)
+        groups, mults = named_lr_groups(model, head_lr_mult)
+        lowp = self.compute_dtype if self.compute_dtype != torch.float32 else None
+        self.ddp = DistributedDataParallel(model, groups, bucket_bytes=bucket_mb << 20, lowp_dtype=lowp,
+                                           process_group=process_group)
+        self.model = model
+        self.criterion = criterion
+        self.optimizer = FlatSGD(self.ddp.arena, [lr * m for m in mults], momentum, weight_decay)
+        self.accum_steps = max(int(accum_steps), 1)
+        self._micro = 0
+        self.timer = PhaseTimer(self.on_gpu, markers)
+        self.global_step = 0
+
+    # ------------------------------------------------------------------
+    def prepare_input(self, images: torch.Tensor) -> torch.Tensor:
+        x = images.to(self.device, non_blocking=True)
+        if x.dtype != self.compute_dtype:
+            x = x.to(self.compute_dtype)
+        if self.on_gpu and x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+        return x
+
+    def train_step(self, images: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        self.model.train()
+        x = self.prepare_input(images)
+        # TODO `train_pascal.py:5`: "label non_blocking = True"
+        y = target.to(self.device, non_blocking=True)
+        last_micro = (self._micro + 1) % self.accum_steps == 0
+        with self.timer.phase("fwd"):
+            out = self.ddp(x)
+            loss = self.criterion(out, y)
+            if self.accum_steps > 1:
+                loss = loss / self.accum_steps
+        with self.timer.phase("bwd"):
+            if last_micro:
+                loss.backward()
+            else:
+                with self.ddp.no_sync():
+                    loss.backward()
+        self._micro += 1
+        if last_micro:
+            with self.timer.phase("comm_wait"):
+                scale = self.ddp.finish_gradient_sync()
+            with self.timer.phase("optim"):
+                self.optimizer.step(grad_scale=scale, zero_grad=True)
+            self.global_step += 1
+        return loss.detach()
+
+    @torch.no_grad()
+    def evaluate(self, loader: Iterable, num_classes: int, ignore_index: int = 255,
+                 max_batches: Optional[int] = None) -> Dict[str, float]:
+        """21-class mIoU from a device confusion matrix, merged across ranks (K12 + C6)."""
+        self.model.eval()
+        cm = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=self.device)
+        loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+        n = 0
+        for i, batch in enumerate(loader):
+            if max_batches is not None and i >= max_batches:
+                break
+            images, target = batch if isinstance(batch, (tuple, list)) else (batch["image"], batch["label"])
+            x = self.prepare_input(images)
+            y = target.to(self.device, non_blocking=True)
+            out = self.model(x)
+            loss_sum += self.criterion(out, y).double()
+            logits = out[0] if isinstance(out, (tuple, list)) else out
+            confusion_matrix(logits, y, num_classes, ignore_index, out=cm)
+            n += 1
+        if dist_env.get_world_size() > 1:
+            import torch.distributed as dist
+            packed = torch.cat([cm.view(-1).double(), loss_sum.view(1), loss_sum.new_tensor([float(n)])])
+            dist.all_reduce(packed)
+            cm = packed[:-2].view(num_classes, num_classes).round().long()
+            loss_sum, n = packed[-2], float(packed[-1].item())
+        miou, iou, acc = miou_from_confusion(cm)
+        return {"miou": miou, "pixel_acc": acc, "loss": float(loss_sum.item()) / max(n, 1),
+                "per_class_iou": [float(v) for v in iou.tolist()]}

@@ -1,0 +1,117 @@
+"""Checkpointing compatible with the reference's key space.
+
+The reference saves ``torch.save(net.state_dict(), path)`` of a ``DataParallel``-wrapped net
+(`/root/reference/train_pascal.py:92`, `:230`, `:304`) and loads with
+``net.load_state_dict(torch.load(path))`` after wrapping (`:103`) — i.e. a flat
+``OrderedDict[str, Tensor]`` whose keys all start with ``module.``, fp32, CPU-loadable.  The weights
+file written here is exactly that (contiguous NCHW tensors, regardless of the channels-last arena
+layout used for training).  Everything the reference does NOT save — optimiser momentum, epoch,
+LR position, RNG, best metric — goes to a *sidecar* ``<path>.state`` so the weights file stays
+loadable by the reference.  Rank 0 writes, atomically (tmp + rename), between two barriers (C5).
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ..parallel import dist_env
+
+PREFIX = "module."
+
+
+def _unwrap(model: nn.Module) -> nn.Module:
+    return model.module if hasattr(model, "module") and isinstance(model.module, nn.Module) else model
+
+
+def reference_state_dict(model: nn.Module) -> "OrderedDict[str, torch.Tensor]":
+    """``module.``-prefixed, fp32/int64, contiguous, CPU tensors."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in _unwrap(model).state_dict().items():
+        t = v.detach()
+        if t.is_floating_point():
+            t = t.float()
+        out[PREFIX + k] = t.cpu().contiguous().clone()
+    return out
+
+
+def strip_prefix(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    return OrderedDict((k[len(PREFIX):] if k.startswith(PREFIX) else k, v) for k, v in sd.items())
+
+
+def _atomic_save(obj: Any, path: str) -> None:
+    tmp = f"{path}.tmp.{os.getpid()}"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+def save_checkpoint(path: str, model: nn.Module, optimizer=None, extra: Optional[Dict] = None,
+                    sync: bool = True) -> None:
+    """Weights → ``path`` (reference-loadable); optimiser/epoch/RNG → ``path + '.state'``."""
+    if sync:
+        dist_env.barrier()
+    if dist_env.is_master():
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        _atomic_save(reference_state_dict(model), path)
+        side: Dict[str, Any] = {"extra": dict(extra or {}),
+                                "rng_cpu": torch.get_rng_state()}
+        if optimizer is not None:
+            side["optimizer"] = optimizer.state_dict()
+        _atomic_save(side, path + ".state")
+    if sync:
+        dist_env.barrier()
+
+
+def load_weights(path: str, model: nn.Module, strict: bool = True, map_location="cpu"):
+    """Accepts prefixed or un-prefixed keys, a bare state_dict or ``{'state_dict': ...}``
+    (`/root/reference/train_pascal.py:103-104`).  Files are read with ``weights_only=True``."""
+    obj = torch.load(path, map_location=map_location, weights_only=True)
+    if isinstance(obj, dict) and "state_dict" in obj and not torch.is_tensor(obj["state_dict"]):
+        obj = obj["state_dict"]
+    target = _unwrap(model)
+    result = target.load_state_dict(strip_prefix(obj), strict=strict)
+    arena = getattr(model, "arena", None)
+    if arena is not None:
+        arena.refresh_lowp()
+    return result
+
+
+def load_checkpoint(path: str, model: nn.Module, optimizer=None, strict: bool = True) -> Dict:
+    load_weights(path, model, strict)
+    extra: Dict = {}
+    side_path = path + ".state"
+    if os.path.isfile(side_path):
+        side = torch.load(side_path, map_location="cpu", weights_only=True)
+        extra = side.get("extra", {})
+        if optimizer is not None and "optimizer" in side:
+            optimizer.load_state_dict(side["optimizer"])
+        if "rng_cpu" in side:
+            torch.set_rng_state(side["rng_cpu"])
+    return extra
+
+
+def run_dir(save_dir_root: str, resume_epoch: int = 0) -> str:
+    """``run_<N>`` auto-increment as in `/root/reference/train_pascal.py:73-82`, made race-free:
+    only rank 0 scans/creates, the choice is broadcast."""
+    import glob
+
+    import torch.distributed as dist
+    choice = [None]
+    if dist_env.is_master():
+        if resume_epoch == 0:
+            ids = []
+            for d in glob.glob(os.path.join(save_dir_root, "run_*")):
+                tail = d.rsplit("_", 1)[-1]
+                if tail.isdigit():
+                    ids.append(int(tail))
+            run_id = max(ids) + 1 if ids else 0
+        else:
+            run_id = 0
+        choice[0] = os.path.join(save_dir_root, f"run_{run_id}")
+        os.makedirs(os.path.join(choice[0], "models"), exist_ok=True)
+    if dist_env.get_world_size() > 1:
+        dist.broadcast_object_list(choice, src=0)
+    return choice[0]

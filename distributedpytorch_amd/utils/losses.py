@@ -1,0 +1,66 @@
+"""Loss functions named by the reference.
+
+* ``SegmentationMultiLosses(nclass)`` — imported from the absent ``layers.loss_weighted`` and used
+  as ``criterion.forward(output, gts)`` on DANet's 3-tuple (`/root/reference/train_pascal.py:33`,
+  `:119`, `:199`): a weighted sum of one loss per head.  ``nclass == 1`` (the reference's binary
+  instance task) uses the class-balanced BCE below; ``nclass > 1`` uses the ignore-index softmax CE
+  kernel (ops.loss, K7).
+* ``class_balanced_cross_entropy_loss(output, label, size_average, batch_average)`` — the
+  DEXTR-style balanced BCE that appears in the commented alternatives (`:200-203`, `:250-253`,
+  with the hinted head weights ``l1 + 0.1·l2 + 0.05·l3``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops.loss import softmax_cross_entropy
+
+
+def class_balanced_cross_entropy_loss(output: torch.Tensor, label: torch.Tensor, size_average: bool = True,
+                                      batch_average: bool = True,
+                                      void_pixels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Balanced sigmoid cross-entropy: positives weighted by the negative fraction and vice versa."""
+    if output.shape != label.shape:
+        raise ValueError(f"shape mismatch {tuple(output.shape)} vs {tuple(label.shape)}")
+    x = output.float()
+    pos = (label >= 0.5).float()
+    neg = 1.0 - pos
+    if void_pixels is not None:
+        keep = (void_pixels < 0.5).float()
+        pos, neg = pos * keep, neg * keep
+    n_pos, n_neg = pos.sum(), neg.sum()
+    total = (n_pos + n_neg).clamp_min(1.0)
+    per_px = F.softplus(-x.abs()) + torch.relu(x) - x * (label >= 0.5).float()  # stable BCE-with-logits
+    loss = (n_neg / total) * (pos * per_px).sum() + (n_pos / total) * (neg * per_px).sum()
+    if size_average:
+        loss = loss / float(label.numel())
+    elif batch_average:
+        loss = loss / float(label.shape[0])
+    return loss
+
+
+class SegmentationMultiLosses(nn.Module):
+    def __init__(self, nclass: int = 21, weights: Sequence[float] = (1.0, 1.0, 1.0), ignore_index: int = 255):
+        super().__init__()
+        self.nclass, self.weights, self.ignore_index = nclass, tuple(weights), ignore_index
+
+    def _one(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if self.nclass == 1:
+            return class_balanced_cross_entropy_loss(pred, target.view_as(pred).float(),
+                                                     size_average=False, batch_average=True)
+        if target.dim() == 4:
+            target = target[:, 0]
+        return softmax_cross_entropy(pred, target, self.ignore_index)
+
+    def forward(self, outputs, target):
+        if torch.is_tensor(outputs):
+            outputs = (outputs,)
+        total = None
+        for w, o in zip(self.weights, outputs):
+            term = self._one(o, target) * w
+            total = term if total is None else total + term
+        return total
