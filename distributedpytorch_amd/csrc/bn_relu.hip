@@ -1,0 +1,372 @@
+// Fused BatchNorm kernels for NHWC bf16 activations on gfx950.
+//
+// All four kernels share ONE thread→data mapping: the activation is an [M, C] row-major matrix
+// (M = N·H·W), viewed as 16-byte chunks of 8 channels.  A thread owns a fixed channel group
+// (cg) for its whole life and walks rows with a block-wide stride, so
+//   * every global access is a 16-B vector load/store, consecutive lanes → consecutive chunks
+//     (full 1 KiB per wave-instruction when C ≥ 512, row-contiguous otherwise);
+//   * per-channel constants (scale/shift, a/b/c of the backward) are computed once per thread and
+//     live in registers — no per-element modulo, no constant-memory traffic;
+//   * the reductions accumulate in fp32 registers, combine across the block through LDS and issue
+//     one fp32 atomic per (block, channel): 256-B contiguous atomics per wave-instruction.
+//
+//   stats       x                    -> Σx, Σx²
+//   apply       x,(stats|affine)     -> y = act(x·scale + shift (+res));  block 0 also finalises
+//                                       mean / invstd / running statistics
+//   bwd_reduce  dy, x (,y)           -> Σdy', Σdy'·x̂     (dy' = dy masked by the ReLU)
+//   bwd_apply   dy, x (,y)           -> dx = a·dy' + b·x + c  (, d_residual = dy')
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxRowBlocks = 1024;
+
+struct Map {
+    int cg;      // global channel-group index (8 channels)
+    int rlane;   // row lane inside the block
+    int rpp;     // rows per pass of the block
+    int cgs;     // channel groups handled by this block
+    bool active;
+};
+
+__device__ __forceinline__ Map make_map(int C8) {
+    Map m;
+    const int base = blockIdx.y * kThreads;
+    m.cgs = min(kThreads, C8 - base);
+    m.rpp = kThreads / m.cgs;
+    const int cgl = threadIdx.x % m.cgs;
+    m.rlane = threadIdx.x / m.cgs;
+    m.cg = base + cgl;
+    m.active = m.rlane < m.rpp;
+    return m;
+}
+
+__device__ __forceinline__ uint4 ldg16(const bf16_raw* p, long chunk) {
+    return *reinterpret_cast<const uint4*>(p + chunk * 8);
+}
+__device__ __forceinline__ void stg16(bf16_raw* p, long chunk, const uint4& v) {
+    *reinterpret_cast<uint4*>(p + chunk * 8) = v;
+}
+
+// Block-level combine of NACC per-thread accumulators over row lanes, then atomics.
+template <int NACC>
+__device__ __forceinline__ void block_reduce_atomic(const Map& m, float (&acc)[NACC], float* smem,
+                                                    float* out0, float* out1, int C) {
+    // smem layout [NACC][kThreads]
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) smem[j * kThreads + threadIdx.x] = m.active ? acc[j] : 0.f;
+    __syncthreads();
+    if (m.rlane == 0) {
+        const int cgl = threadIdx.x;  // == cg - base because rlane == 0
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            float s = 0.f;
+            for (int rl = 0; rl < m.rpp; ++rl) s += smem[j * kThreads + rl * m.cgs + cgl];
+            acc[j] = s;
+        }
+        const int c0 = m.cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(out0 + c0 + j, acc[j]);
+            atomicAdd(out1 + c0 + j, acc[8 + j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const bf16_raw* __restrict__ x, long M, int C,
+                                                            float* __restrict__ sum, float* __restrict__ sq) {
+    __shared__ float smem[16 * kThreads];
+    const int C8 = C >> 3;
+    const Map m = make_map(C8);
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    if (m.active) {
+        const long stride = (long)gridDim.x * m.rpp;
+        long r = (long)blockIdx.x * m.rpp + m.rlane;
+        // 4 independent 16-B loads in flight per thread
+        for (; r + 3 * stride < M; r += 4 * stride) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ldg16(x, (r + u * stride) * C8 + m.cg);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[j] += f[j]; acc[8 + j] = fmaf(f[j], f[j], acc[8 + j]); }
+            }
+        }
+        for (; r < M; r += stride) {
+            float f[8];
+            unpack8(ldg16(x, r * C8 + m.cg), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[j] += f[j]; acc[8 + j] = fmaf(f[j], f[j], acc[8 + j]); }
+        }
+    }
+    block_reduce_atomic<16>(m, acc, smem, sum, sq, C);
+}
+
+struct ApplyArgs {
+    const bf16_raw* x; const bf16_raw* res; bf16_raw* y;
+    long M; int C;
+    // FROM_STATS: sum/sq/weight/bias (+ outputs mean/invstd, running stats); else scale/shift
+    const float* sum; const float* sq; const float* weight; const float* bias;
+    const float* scale; const float* shift;
+    float* mean_out; float* invstd_out; float* running_mean; float* running_var;
+    float inv_count, eps, momentum, unbias;
+    int relu;
+};
+
+template <bool FROM_STATS>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
+    const int C8 = a.C >> 3;
+    const Map m = make_map(C8);
+    if (!m.active) return;
+    float sc[8], sh[8];
+    const int c0 = m.cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (FROM_STATS) {
+            const float mean = a.sum[c0 + j] * a.inv_count;
+            const float var = fmaxf(fmaf(-mean, mean, a.sq[c0 + j] * a.inv_count), 0.f);
+            const float invstd = rsqrtf(var + a.eps);
+            const float w = a.weight ? a.weight[c0 + j] : 1.f;
+            const float b = a.bias ? a.bias[c0 + j] : 0.f;
+            sc[j] = w * invstd;
+            sh[j] = fmaf(-mean, sc[j], b);
+            if (blockIdx.x == 0 && m.rlane == 0) {
+                a.mean_out[c0 + j] = mean;
+                a.invstd_out[c0 + j] = invstd;
+                if (a.running_mean) {
+                    a.running_mean[c0 + j] = fmaf(a.momentum, mean - a.running_mean[c0 + j], a.running_mean[c0 + j]);
+                    const float uv = var * a.unbias;
+                    a.running_var[c0 + j] = fmaf(a.momentum, uv - a.running_var[c0 + j], a.running_var[c0 + j]);
+                }
+            }
+        } else {
+            sc[j] = a.scale[c0 + j];
+            sh[j] = a.shift[c0 + j];
+        }
+    }
+    const long stride = (long)gridDim.x * m.rpp;
+    const bool has_res = a.res != nullptr;
+    for (long r = (long)blockIdx.x * m.rpp + m.rlane; r < a.M; r += 2 * stride) {
+        const long q0 = r * C8 + m.cg;
+        const bool second = r + stride < a.M;
+        const long q1 = second ? (r + stride) * C8 + m.cg : q0;
+        uint4 v0 = ldg16(a.x, q0), v1 = ldg16(a.x, q1);
+        uint4 r0 = v0, r1 = v1;
+        if (has_res) { r0 = ldg16(a.res, q0); r1 = ldg16(a.res, q1); }
+        float f0[8], f1[8], g0[8], g1[8];
+        unpack8(v0, f0); unpack8(v1, f1);
+        if (has_res) { unpack8(r0, g0); unpack8(r1, g1); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y0 = fmaf(f0[j], sc[j], sh[j]);
+            float y1 = fmaf(f1[j], sc[j], sh[j]);
+            if (has_res) { y0 += g0[j]; y1 += g1[j]; }
+            if (a.relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+            f0[j] = y0; f1[j] = y1;
+        }
+        stg16(a.y, q0, pack8(f0));
+        if (second) stg16(a.y, q1, pack8(f1));
+    }
+}
+
+struct BwdArgs {
+    const bf16_raw* dy; const bf16_raw* x; const bf16_raw* y;  // y: mask source (mask_mode 1)
+    bf16_raw* dx; bf16_raw* dres;
+    long M; int C;
+    const float* mean; const float* invstd; const float* weight; const float* bias;
+    const float* sdy; const float* sdyx;   // bwd_apply inputs (null => frozen statistics)
+    float* out_sdy; float* out_sdyx;       // bwd_reduce outputs
+    float inv_count;
+    int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0
+};
+
+__device__ __forceinline__ void masked_dy(const BwdArgs& a, int mode, const float* sc, const float* sh,
+                                          const float* xf, const uint4& yv, float* dyf) {
+    if (mode == 1) {
+        float yf[8];
+        unpack8(yv, yf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dyf[j] = yf[j] > 0.f ? dyf[j] : 0.f;
+    } else if (mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dyf[j] = fmaf(xf[j], sc[j], sh[j]) > 0.f ? dyf[j] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
+    __shared__ float smem[16 * kThreads];
+    const int C8 = a.C >> 3;
+    const Map m = make_map(C8);
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    if (m.active) {
+        const int c0 = m.cg * 8;
+        float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = a.mean[c0 + j];
+            is[j] = a.invstd[c0 + j];
+            const float w = a.weight ? a.weight[c0 + j] : 1.f;
+            const float b = a.bias ? a.bias[c0 + j] : 0.f;
+            sc[j] = w * is[j];
+            sh[j] = fmaf(-mu[j], sc[j], b);
+        }
+        const long stride = (long)gridDim.x * m.rpp;
+        for (long r = (long)blockIdx.x * m.rpp + m.rlane; r < a.M; r += 2 * stride) {
+            const long q0 = r * C8 + m.cg;
+            const bool second = r + stride < a.M;
+            const long q1 = second ? (r + stride) * C8 + m.cg : q0;
+            uint4 d0 = ldg16(a.dy, q0), d1 = ldg16(a.dy, q1);
+            uint4 x0 = ldg16(a.x, q0), x1 = ldg16(a.x, q1);
+            uint4 y0 = x0, y1 = x1;
+            if (a.mask_mode == 1) { y0 = ldg16(a.y, q0); y1 = ldg16(a.y, q1); }
+            float df[8], xf[8];
+            unpack8(d0, df); unpack8(x0, xf);
+            masked_dy(a, a.mask_mode, sc, sh, xf, y0, df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] += df[j];
+                acc[8 + j] = fmaf(df[j], (xf[j] - mu[j]) * is[j], acc[8 + j]);
+            }
+            if (second) {
+                unpack8(d1, df); unpack8(x1, xf);
+                masked_dy(a, a.mask_mode, sc, sh, xf, y1, df);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[j] += df[j];
+                    acc[8 + j] = fmaf(df[j], (xf[j] - mu[j]) * is[j], acc[8 + j]);
+                }
+            }
+        }
+    }
+    block_reduce_atomic<16>(m, acc, smem, a.out_sdy, a.out_sdyx, a.C);
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
+    const int C8 = a.C >> 3;
+    const Map m = make_map(C8);
+    if (!m.active) return;
+    const int c0 = m.cg * 8;
+    float ka[8], kb[8], kc[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float mu = a.mean[c0 + j], is = a.invstd[c0 + j];
+        const float w = a.weight ? a.weight[c0 + j] : 1.f;
+        const float b = a.bias ? a.bias[c0 + j] : 0.f;
+        sc[j] = w * is;
+        sh[j] = fmaf(-mu, sc[j], b);
+        ka[j] = sc[j];
+        if (a.sdy) {
+            kb[j] = -sc[j] * is * a.sdyx[c0 + j] * a.inv_count;
+            kc[j] = -sc[j] * a.sdy[c0 + j] * a.inv_count - kb[j] * mu;
+        } else {
+            kb[j] = 0.f; kc[j] = 0.f;
+        }
+    }
+    const long stride = (long)gridDim.x * m.rpp;
+    for (long r = (long)blockIdx.x * m.rpp + m.rlane; r < a.M; r += 2 * stride) {
+        const long q0 = r * C8 + m.cg;
+        const bool second = r + stride < a.M;
+        const long q1 = second ? (r + stride) * C8 + m.cg : q0;
+        uint4 d0 = ldg16(a.dy, q0), d1 = ldg16(a.dy, q1);
+        uint4 x0 = ldg16(a.x, q0), x1 = ldg16(a.x, q1);
+        uint4 y0 = x0, y1 = x1;
+        if (a.mask_mode == 1) { y0 = ldg16(a.y, q0); y1 = ldg16(a.y, q1); }
+        float df[8], xf[8], o[8];
+        unpack8(d0, df); unpack8(x0, xf);
+        masked_dy(a, a.mask_mode, sc, sh, xf, y0, df);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(ka[j], df[j], fmaf(kb[j], xf[j], kc[j]));
+        stg16(a.dx, q0, pack8(o));
+        if (a.dres) stg16(a.dres, q0, pack8(df));
+        if (second) {
+            unpack8(d1, df); unpack8(x1, xf);
+            masked_dy(a, a.mask_mode, sc, sh, xf, y1, df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf(ka[j], df[j], fmaf(kb[j], xf[j], kc[j]));
+            stg16(a.dx, q1, pack8(o));
+            if (a.dres) stg16(a.dres, q1, pack8(df));
+        }
+    }
+}
+
+inline dim3 grid_for(long M, int C, int rows_per_thread) {
+    const int C8 = C / 8;
+    const int cgs = C8 < kThreads ? C8 : kThreads;
+    const int rpp = kThreads / cgs;
+    long nb = (M + (long)rpp * rows_per_thread - 1) / ((long)rpp * rows_per_thread);
+    if (nb < 1) nb = 1;
+    if (nb > kMaxRowBlocks) nb = kMaxRowBlocks;
+    return dim3((unsigned)nb, (unsigned)((C8 + kThreads - 1) / kThreads), 1);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI.  Host-side shape checks live in ops/_hip_bn.py; here only C % 8 is re-checked because a
+// violation would read out of bounds.
+// ---------------------------------------------------------------------------------------------
+DP_EXPORT int dp_bn_stats(const void* x, long M, int C, float* sum, float* sq, hipStream_t st) {
+    if (C % 8 != 0 || M <= 0) return -1;
+    hipLaunchKernelGGL(bn_stats_kernel, grid_for(M, C, 8), dim3(kThreads), 0, st,
+                       (const bf16_raw*)x, M, C, sum, sq);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M, int C, const float* sum,
+                                const float* sq, const float* weight, const float* bias, float* mean_out,
+                                float* invstd_out, float* running_mean, float* running_var, float count,
+                                float eps, float momentum, int relu, hipStream_t st) {
+    if (C % 8 != 0 || M <= 0) return -1;
+    ApplyArgs a{};
+    a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
+    a.sum = sum; a.sq = sq; a.weight = weight; a.bias = bias;
+    a.mean_out = mean_out; a.invstd_out = invstd_out; a.running_mean = running_mean; a.running_var = running_var;
+    a.inv_count = 1.f / count; a.eps = eps; a.momentum = momentum;
+    a.unbias = count > 1.f ? count / (count - 1.f) : 1.f;
+    a.relu = relu;
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bn_apply_affine(const void* x, const void* res, void* y, long M, int C, const float* scale,
+                                 const float* shift, int relu, hipStream_t st) {
+    if (C % 8 != 0 || M <= 0) return -1;
+    ApplyArgs a{};
+    a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
+    a.scale = scale; a.shift = shift; a.relu = relu;
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, long M, int C, const float* mean,
+                               const float* invstd, const float* weight, const float* bias, float* out_sdy,
+                               float* out_sdyx, int mask_mode, hipStream_t st) {
+    if (C % 8 != 0 || M <= 0) return -1;
+    BwdArgs a{};
+    a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y; a.M = M; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias;
+    a.out_sdy = out_sdy; a.out_sdyx = out_sdyx; a.mask_mode = mask_mode;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid_for(M, C, 8), dim3(kThreads), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, void* dres, long M, int C,
+                              const float* mean, const float* invstd, const float* weight, const float* bias,
+                              const float* sdy, const float* sdyx, float count, int mask_mode, hipStream_t st) {
+    if (C % 8 != 0 || M <= 0) return -1;
+    BwdArgs a{};
+    a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y;
+    a.dx = (bf16_raw*)dx; a.dres = (bf16_raw*)dres; a.M = M; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias; a.sdy = sdy; a.sdyx = sdyx;
+    a.inv_count = 1.f / count; a.mask_mode = mask_mode;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}

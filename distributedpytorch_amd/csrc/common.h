@@ -1,0 +1,52 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DP_EXPORT extern "C" __attribute__((visibility("default")))
+
+typedef unsigned short bf16_raw;  // storage type: tensors are passed as raw 16-bit words
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+static constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf2f(bf16_raw u) { return __uint_as_float(((unsigned)u) << 16); }
+
+// plain cast: hipcc -O3 emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+__device__ __forceinline__ bf16_raw f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2(f[0], f[1]); v.y = pack2(f[2], f[3]);
+    v.z = pack2(f[4], f[5]); v.w = pack2(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Launch-status helper: launchers return hipGetLastError() as int (0 = ok).
+#define DP_LAUNCH_STATUS() ((int)hipGetLastError())

@@ -1,0 +1,237 @@
+// Implicit-GEMM convolution weight gradient on MFMA for gfx950.
+//
+//   dW[k, (r,s,c)] = Σ_p dY[p, k] · X[pin(p, r, s), c]        p over batch·Ho·Wo output pixels
+//
+// GEMM view: M' = Cout, N' = R·S·Cin (the flattened KRSC weight row — tiles may straddle taps, so
+// Cin = 8, 64 or 304 waste nothing), K' = pixels (very deep → split-K over pixel ranges).
+//
+// Both operands arrive "K-major": a pixel is a row and its channels are contiguous, but the MFMA
+// fragments need 8 consecutive PIXELS per lane.  The tiles are therefore staged [pixel][channel]
+// exactly as they lie in memory (global_load_lds_dwordx4, 16 B per lane) and read back with the
+// CDNA4 transposing LDS read ds_read_b64_tr_b16 (4 pixels × 16 channels per 16-lane group, delivered
+// pixel-major per lane) — no register shuffles, no pre-transposed copies of activations.
+// LDS image: 256-B rows (128 channels), 16-B chunk index XOR-swizzled with
+// f(row) = ((row&3)<<2)|((row>>2)&3) on the load SOURCE side and on the read side, which makes the
+// transposed reads conflict-free.
+//
+// Split-K: each block owns (k-tile, n-tile, pixel range) and adds its fp32 128×128 partial tile into
+// dW with no-return fp32 atomics; one accumulator register is two 128-B contiguous segments per
+// wave-instruction, the shape that runs at the full atomic rate on MI355X.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int TM = 128;   // Cout tile
+constexpr int TN = 128;   // flattened (r,s,c) tile
+constexpr int TP = 64;    // pixels per K-step
+constexpr int TILE_BYTES = TP * 256;        // one operand tile: 64 rows × 256 B
+constexpr int STAGE = 2 * TILE_BYTES;
+
+__device__ uint4 g_zero_page_w[16];
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradArgs {
+    const bf16_raw* dy;   // [P, Cout]
+    const bf16_raw* x;    // [N, Hi, Wi, Cin]
+    float* dw;            // [Cout, R*S*Cin]
+    int P;                // N*Ho*Wo
+    int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
+    int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int NF;               // R*S*Cin
+    int tiles_k, tiles_n, splits, px_per_split;   // px_per_split multiple of TP
+};
+
+__device__ __forceinline__ void glds16w(const bf16_raw* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)src,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int off0, int off1) {
+    // two transposing reads = the 8 consecutive pixels of one channel this lane needs
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + off1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- block → (split, n-tile, k-tile); XCD-aware so one XCD's blocks share a pixel range ----
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles = p.tiles_k * p.tiles_n;
+    const int split = bid / tiles;
+    const int tile = bid - split * tiles;
+    const int tile_k = tile % p.tiles_k, tile_n = tile / p.tiles_k;
+    const int k0 = tile_k * TM, n0 = tile_n * TN;
+    const int p_begin = split * p.px_per_split;
+    const int p_end = min(p.P, p_begin + p.px_per_split);
+    const int nsteps = (p_end - p_begin + TP - 1) / TP;
+
+    // ---- load geometry: a wave-instruction fills 4 rows × 256 B ----
+    const int pc = lane & 15;                       // physical chunk
+    const int rsub = lane >> 4;                     // row within the 4-row group
+    const int fsw = (rsub << 2) | wave;             // f(row): row&3 = rsub, (row>>2)&3 = wave
+    const int lc = pc ^ fsw;                        // logical chunk fetched by this lane
+    const bf16_raw* zero = reinterpret_cast<const bf16_raw*>(g_zero_page_w) + (pc & 7) * 8;
+
+    // dy operand: channel k0 + lc*8
+    const int kch = k0 + lc * 8;
+    const unsigned k_ok = (unsigned)(kch < p.Cout);
+    // x operand: flattened weight-row index → (tap, c)
+    const int flat = n0 + lc * 8;
+    const unsigned n_ok = (unsigned)(flat < p.NF);
+    const int tap = flat / p.Cin;
+    const int cch = flat - tap * p.Cin;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int tdy = tr * p.dil_h - p.pad_h, tdx = ts * p.dil_w - p.pad_w;
+
+    // per-round pixel state (row = round*16 + wave*4 + rsub), advanced incrementally by TP per step
+    int px[4], pox[4], poy[4], pn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        px[i] = p_begin + i * 16 + wave * 4 + rsub;
+        pox[i] = px[i] % p.Wo;
+        const int t = px[i] / p.Wo;
+        poy[i] = t % p.Ho;
+        pn[i] = t / p.Ho;
+    }
+    const int adv_x = TP % p.Wo, adv_y = TP / p.Wo;
+
+    auto issue_stage = [&](int buf) {
+        unsigned char* dbase = smem + buf * STAGE + wave * 1024;   // dy tile
+        unsigned char* xbase = dbase + TILE_BYTES;                 // x tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned p_ok = (unsigned)(px[i] < p_end);
+            const unsigned okd = p_ok & k_ok;
+            glds16w(okd ? p.dy + (px[i] * p.Cout + kch) : zero, dbase + i * 4096);
+            const int iy = poy[i] * p.stride_h + tdy, ix = pox[i] * p.stride_w + tdx;
+            const unsigned okx = p_ok & n_ok & (unsigned)((unsigned)iy < (unsigned)p.Hi) &
+                                 (unsigned)((unsigned)ix < (unsigned)p.Wi);
+            glds16w(okx ? p.x + (((pn[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + cch) : zero, xbase + i * 4096);
+            // advance this row's pixel by TP
+            px[i] += TP;
+            pox[i] += adv_x; poy[i] += adv_y;
+            if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; }
+            while (poy[i] >= p.Ho) { poy[i] -= p.Ho; pn[i] += 1; }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // ---- fragment read geometry (see file header): group g = lane>>4, q = (lane&15)>>2, pp = lane&3
+    const int wm = wave >> 1, wn = wave & 1;             // 2×2 waves, each 64(k) × 64(n)
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    // row (pixel) inside a 16-pixel k-block for read rd: 8*(g>>1) + 4*rd + q
+    // physical chunk = (cb/8 + 2*(g&1) + (pp>>1)) ^ ((q<<2) | ((2*(g>>1) + rd) & 3))
+    int offA[2][2], offB[2][2];                          // [sub-tile][rd]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int row = 8 * (g >> 1) + 4 * rd + q;
+            const int f = (q << 2) | ((2 * (g >> 1) + rd) & 3);
+            const int chA = ((wm * 64 + t * 32) >> 3) + 2 * (g & 1) + (pp >> 1);
+            const int chB = ((wn * 64 + t * 32) >> 3) + 2 * (g & 1) + (pp >> 1);
+            offA[t][rd] = row * 256 + ((chA ^ f) << 4) + (pp & 1) * 8;
+            offB[t][rd] = row * 256 + ((chB ^ f) << 4) + (pp & 1) * 8;
+        }
+    }
+
+    if (nsteps > 0) issue_stage(0);
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1;
+        __syncthreads();
+        if (t + 1 < nsteps) issue_stage(buf ^ 1);
+        const unsigned char* Ds = smem + buf * STAGE;
+        const unsigned char* Xs = Ds + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < TP / 16; ++kk) {
+            const int kb = kk * 16 * 256;   // 16 pixel rows per MFMA K block
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = tr_frag(Ds + kb, offA[i][0], offA[i][1]);
+                bfr[i] = tr_frag(Xs + kb, offB[i][0], offB[i][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- split-K combine: fp32 atomics, 2 × 128-B contiguous segments per wave-instruction ----
+    const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                if (row < p.Cout && col < p.NF) atomicAdd(p.dw + (long)row * p.NF + col, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// splits: 0 = auto.  dw must be zero-initialised (or hold a gradient to accumulate into).
+DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
+                            int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                            int dil_w, int splits, int reserved, hipStream_t st) {
+    if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0 || N <= 0 || Ho <= 0 || Wo <= 0) return -1;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) & 15) return -3;
+    const long P = (long)N * Ho * Wo;
+    if (P >= (1L << 31) / (Cout > Cin ? Cout : Cin) || (long)N * Hi * Wi * Cin >= (1L << 31)) return -4;
+    WgradArgs p{};
+    p.dy = (const bf16_raw*)dy; p.x = (const bf16_raw*)x; p.dw = (float*)dw;
+    p.P = (int)P; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
+    p.stride_h = stride_h; p.stride_w = stride_w; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
+    p.NF = R * S * Cin;
+    p.tiles_k = (Cout + TM - 1) / TM;
+    p.tiles_n = (p.NF + TN - 1) / TN;
+    const int tiles = p.tiles_k * p.tiles_n;
+    const int steps_total = (int)((P + TP - 1) / TP);
+    if (splits <= 0) {
+        // enough blocks for ~3 waves of workgroups over 256 CUs × 2 blocks/CU, but keep ≥ 8 K-steps
+        // per block so the 64 KB atomic epilogue stays amortised
+        int want = (1536 + tiles - 1) / tiles;
+        int max_by_work = steps_total / 8;
+        if (max_by_work < 1) max_by_work = 1;
+        splits = want < max_by_work ? want : max_by_work;
+        if (splits < 1) splits = 1;
+    }
+    int steps_per = (steps_total + splits - 1) / splits;
+    p.px_per_split = steps_per * TP;
+    p.splits = (int)((P + p.px_per_split - 1) / p.px_per_split);
+    const long nwg = (long)tiles * p.splits;
+    if (nwg > 0x7fffffffL) return -4;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, p);
+    return DP_LAUNCH_STATUS();
+}

@@ -1,0 +1,180 @@
+// Depthwise 3×3 (atrous) convolution for NHWC bf16 on gfx950 — the spatial
+// half of every Xception separable unit.  Memory-bound (9 MACs per loaded element), so no MFMA:
+// one thread owns 8 channels of one pixel, every access is a 16-B vector, weights are kept
+// tap-major [9][C] so the 8 channels of a tap are one 16-B load.
+//   fwd        y[n,oy,ox,c]  = Σ_t x[n, oy·s-p+r·d, ox·s-p+q·d, c] · w[t][c]
+//   bwd_data   dx[n,iy,ix,c] = Σ_t dy[n,(iy+p-r·d)/s,(ix+p-q·d)/s,c] · w[t][c]   (where divisible)
+//   bwd_weight dw[t][c]      = Σ_{n,oy,ox} dy · x      (column reduction, same mapping as BN stats)
+#include "common.h"
+
+namespace {
+
+struct Dw { int N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil; };
+
+inline int grid_1d(long total, int threads, int cap = 256 * 16) {
+    long b = (total + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w9,
+                                                         bf16_raw* __restrict__ y, Dw p) {
+    const int C8 = p.C >> 3;
+    const long total = (long)p.N * p.Ho * p.Wo * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C8);
+        long pix = i / C8;
+        const int ox = (int)(pix % p.Wo); pix /= p.Wo;
+        const int oy = (int)(pix % p.Ho);
+        const int n = (int)(pix / p.Ho);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * p.stride - p.pad_h + r * p.dil;
+            if ((unsigned)iy >= (unsigned)p.Hi) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ix = ox * p.stride - p.pad_w + q * p.dil;
+                if ((unsigned)ix >= (unsigned)p.Wi) continue;
+                float xv[8], wv[8];
+                unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cg * 8), xv);
+                unpack8(*reinterpret_cast<const uint4*>(w9 + (r * 3 + q) * p.C + cg * 8), wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+            }
+        }
+        reinterpret_cast<uint4*>(y)[i] = pack8(acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16_raw* __restrict__ dy,
+                                                              const bf16_raw* __restrict__ w9,
+                                                              bf16_raw* __restrict__ dx, Dw p) {
+    const int C8 = p.C >> 3;
+    const long total = (long)p.N * p.Hi * p.Wi * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C8);
+        long pix = i / C8;
+        const int ix = (int)(pix % p.Wi); pix /= p.Wi;
+        const int iy = (int)(pix % p.Hi);
+        const int n = (int)(pix / p.Hi);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ty = iy + p.pad_h - r * p.dil;
+            if (ty < 0 || ty % p.stride) continue;
+            const int oy = ty / p.stride;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int tx = ix + p.pad_w - q * p.dil;
+                if (tx < 0 || tx % p.stride) continue;
+                const int ox = tx / p.stride;
+                if (ox >= p.Wo) continue;
+                float dv[8], wv[8];
+                unpack8(*reinterpret_cast<const uint4*>(dy + (((long)n * p.Ho + oy) * p.Wo + ox) * p.C + cg * 8), dv);
+                unpack8(*reinterpret_cast<const uint4*>(w9 + (r * 3 + q) * p.C + cg * 8), wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(dv[j], wv[j], acc[j]);
+            }
+        }
+        reinterpret_cast<uint4*>(dx)[i] = pack8(acc);
+    }
+}
+
+// thread = (channel group, row lane); rows = output pixels; 9 taps × 8 channels of fp32 partials
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_raw* __restrict__ dy,
+                                                                const bf16_raw* __restrict__ x,
+                                                                float* __restrict__ dw9, Dw p) {
+    __shared__ float smem[8 * 256];
+    const int C8 = p.C >> 3;
+    const int base = blockIdx.y * 256;
+    const int cgs = min(256, C8 - base);
+    const int rpp = 256 / cgs;
+    const int cgl = threadIdx.x % cgs, rlane = threadIdx.x / cgs;
+    const int cg = base + cgl;
+    const bool active = rlane < rpp;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    const long P = (long)p.N * p.Ho * p.Wo;
+    if (active) {
+        for (long r = (long)blockIdx.x * rpp + rlane; r < P; r += (long)gridDim.x * rpp) {
+            const int ox = (int)(r % p.Wo);
+            const long t2 = r / p.Wo;
+            const int oy = (int)(t2 % p.Ho);
+            const int n = (int)(t2 / p.Ho);
+            float dv[8];
+            unpack8(*reinterpret_cast<const uint4*>(dy + r * p.C + cg * 8), dv);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int iy = oy * p.stride - p.pad_h + a * p.dil;
+                if ((unsigned)iy >= (unsigned)p.Hi) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int ix = ox * p.stride - p.pad_w + q * p.dil;
+                    if ((unsigned)ix >= (unsigned)p.Wi) continue;
+                    float xv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cg * 8), xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[a * 3 + q][j] = fmaf(dv[j], xv[j], acc[a * 3 + q][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) smem[j * 256 + threadIdx.x] = active ? acc[t][j] : 0.f;
+        __syncthreads();
+        if (rlane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.f;
+                for (int rl = 0; rl < rpp; ++rl) s += smem[j * 256 + rl * cgs + cgl];
+                atomicAdd(dw9 + t * p.C + cg * 8 + j, s);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                            int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
+    Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_1d((long)N * Ho * Wo * (C / 8), 256)), dim3(256), 0, st,
+                       (const bf16_raw*)x, (const bf16_raw*)w9, (bf16_raw*)y, p);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N, int C, int Hi, int Wi, int Ho,
+                                 int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
+    Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
+    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_1d((long)N * Hi * Wi * (C / 8), 256)), dim3(256), 0, st,
+                       (const bf16_raw*)dy, (const bf16_raw*)w9, (bf16_raw*)dx, p);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int N, int C, int Hi, int Wi, int Ho,
+                                   int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
+    Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
+    const int C8 = C / 8;
+    const int cgs = C8 < 256 ? C8 : 256;
+    const int rpp = 256 / cgs;
+    long nb = ((long)N * Ho * Wo + (long)rpp * 8 - 1) / ((long)rpp * 8);
+    if (nb < 1) nb = 1;
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3((unsigned)nb, (unsigned)((C8 + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p);
+    return DP_LAUNCH_STATUS();
+}

@@ -1,0 +1,308 @@
+// Ignore-index softmax cross-entropy (K7) and bilinear resize, align_corners=True (K6), for NHWC
+// bf16 tensors on gfx950.
+//
+// softmax-CE: logits are an [M, C] row-major matrix with C small (21) so a row is 42 bytes — not a
+// vector-load-friendly stride.  A 256-thread block therefore stages 256 consecutive rows (a
+// contiguous, 16-B-aligned slab of 256·C·2 bytes) through LDS with coalesced 16-B loads, then each
+// thread owns one pixel and walks its row in LDS (stride C·2 B → banks spread).  Forward produces
+// Σloss and the valid-pixel count (one atomic pair per block); backward recomputes the softmax
+// from the logits (cheaper than materialising dlogits in forward: 3 passes over the logits in
+// total instead of 4, and no activation memory held between forward and backward) and writes
+// dlogits = (p - onehot) · gloss / count, staged back through LDS for coalesced stores.
+//
+// bilinear: forward is a 4-tap gather; backward is scatter-free — every INPUT pixel gathers the
+// output pixels whose footprint covers it (window ≤ ⌈2/r⌉ per axis) so there are no atomics and
+// the result is deterministic.  Channels are vectorised 8-wide when C % 8 == 0; the logits map
+// (C = 21) takes the scalar path.
+#include "common.h"
+
+namespace {
+
+constexpr int kCeThreads = 256;
+
+template <typename LabelT>
+__device__ __forceinline__ int load_label(const void* p, long i) {
+    return (int)reinterpret_cast<const LabelT*>(p)[i];
+}
+
+__device__ __forceinline__ void stage_rows_in(const bf16_raw* __restrict__ g, bf16_raw* lds, long row0, long M,
+                                              int C) {
+    // slab of up to 256 rows: [row0, row0+256) ∩ [0, M); base is 16-B aligned because 256·C·2 is
+    const long rows = min((long)kCeThreads, M - row0);
+    const long elems = rows * C;
+    const bf16_raw* src = g + row0 * C;
+    const long vec = elems >> 3;
+    for (long i = threadIdx.x; i < vec; i += kCeThreads)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (long i = (vec << 3) + threadIdx.x; i < elems; i += kCeThreads) lds[i] = src[i];
+}
+
+__device__ __forceinline__ void stage_rows_out(bf16_raw* __restrict__ g, const bf16_raw* lds, long row0, long M,
+                                               int C) {
+    const long rows = min((long)kCeThreads, M - row0);
+    const long elems = rows * C;
+    bf16_raw* dst = g + row0 * C;
+    const long vec = elems >> 3;
+    for (long i = threadIdx.x; i < vec; i += kCeThreads)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(lds)[i];
+    for (long i = (vec << 3) + threadIdx.x; i < elems; i += kCeThreads) dst[i] = lds[i];
+}
+
+// out[0] += Σ loss, out[1] += #valid
+template <typename LabelT>
+__global__ __launch_bounds__(kCeThreads) void softmax_ce_fwd_kernel(const bf16_raw* __restrict__ logits,
+                                                                    const void* __restrict__ target, long M, int C,
+                                                                    int ignore_index, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_raw* tile = reinterpret_cast<bf16_raw*>(smem_raw);
+    float loss = 0.f, cnt = 0.f;
+    for (long row0 = (long)blockIdx.x * kCeThreads; row0 < M; row0 += (long)gridDim.x * kCeThreads) {
+        __syncthreads();
+        stage_rows_in(logits, tile, row0, M, C);
+        __syncthreads();
+        const long r = row0 + threadIdx.x;
+        if (r < M) {
+            const int t = load_label<LabelT>(target, r);
+            if (t != ignore_index && t >= 0 && t < C) {
+                const bf16_raw* row = tile + threadIdx.x * C;
+                float mx = -3.0e38f;
+                for (int c = 0; c < C; ++c) mx = fmaxf(mx, bf2f(row[c]));
+                float s = 0.f;
+                for (int c = 0; c < C; ++c) s += __expf(bf2f(row[c]) - mx);
+                loss += __logf(s) + mx - bf2f(row[t]);
+                cnt += 1.f;
+            }
+        }
+    }
+    loss = wave_sum(loss);
+    cnt = wave_sum(cnt);
+    // reduction scratch lives in the same dynamic LDS block (keeps the carve base 16-B aligned)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);
+    const int wid = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if (lane == 0) { red[wid] = loss; red[8 + wid] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l = 0.f, c = 0.f;
+        for (int w = 0; w < kCeThreads / kWave; ++w) { l += red[w]; c += red[8 + w]; }
+        atomicAdd(out + 0, l);
+        atomicAdd(out + 1, c);
+    }
+}
+
+// dlogits = (softmax - onehot) * gloss / max(count, 1); ignored rows -> 0
+template <typename LabelT>
+__global__ __launch_bounds__(kCeThreads) void softmax_ce_bwd_kernel(const bf16_raw* __restrict__ logits,
+                                                                    const void* __restrict__ target, long M, int C,
+                                                                    int ignore_index, const float* __restrict__ sums,
+                                                                    const float* __restrict__ gloss,
+                                                                    bf16_raw* __restrict__ dlogits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_raw* tile = reinterpret_cast<bf16_raw*>(smem_raw);
+    const float k = gloss[0] / fmaxf(sums[1], 1.f);
+    for (long row0 = (long)blockIdx.x * kCeThreads; row0 < M; row0 += (long)gridDim.x * kCeThreads) {
+        __syncthreads();
+        stage_rows_in(logits, tile, row0, M, C);
+        __syncthreads();
+        const long r = row0 + threadIdx.x;
+        if (r < M) {
+            bf16_raw* row = tile + threadIdx.x * C;
+            const int t = load_label<LabelT>(target, r);
+            if (t != ignore_index && t >= 0 && t < C) {
+                float mx = -3.0e38f;
+                for (int c = 0; c < C; ++c) mx = fmaxf(mx, bf2f(row[c]));
+                float s = 0.f;
+                for (int c = 0; c < C; ++c) s += __expf(bf2f(row[c]) - mx);
+                const float inv = k / s;
+                for (int c = 0; c < C; ++c) {
+                    float p = __expf(bf2f(row[c]) - mx) * inv;
+                    if (c == t) p -= k;
+                    row[c] = f2bf(p);
+                }
+            } else {
+                for (int c = 0; c < C; ++c) row[c] = 0;
+            }
+        }
+        __syncthreads();
+        stage_rows_out(dlogits, tile, row0, M, C);
+    }
+}
+
+// ------------------------------- bilinear, align_corners=True -------------------------------
+struct Resize {
+    int N, C, Hi, Wi, Ho, Wo;
+    float ry, rx;  // input step per output pixel: (Hi-1)/(Ho-1)
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const bf16_raw* __restrict__ x, bf16_raw* __restrict__ y,
+                                                           Resize p) {
+    const int CV = p.C / VEC;
+    const long total = (long)p.N * p.Ho * p.Wo * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long pix = i / CV;
+        const int ox = (int)(pix % p.Wo); pix /= p.Wo;
+        const int oy = (int)(pix % p.Ho);
+        const int n = (int)(pix / p.Ho);
+        const float sy = oy * p.ry, sx = ox * p.rx;
+        const int y0 = min((int)sy, p.Hi - 1), x0 = min((int)sx, p.Wi - 1);
+        const int y1 = min(y0 + 1, p.Hi - 1), x1 = min(x0 + 1, p.Wi - 1);
+        const float fy = sy - y0, fx = sx - x0;
+        const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
+        const bf16_raw* base = x + (long)n * p.Hi * p.Wi * p.C + cv * VEC;
+        const bf16_raw* p00 = base + ((long)y0 * p.Wi + x0) * p.C;
+        const bf16_raw* p01 = base + ((long)y0 * p.Wi + x1) * p.C;
+        const bf16_raw* p10 = base + ((long)y1 * p.Wi + x0) * p.C;
+        const bf16_raw* p11 = base + ((long)y1 * p.Wi + x1) * p.C;
+        bf16_raw* dst = y + (((long)n * p.Ho + oy) * p.Wo + ox) * p.C + cv * VEC;
+        if (VEC == 8) {
+            float a[8], b[8], c[8], d[8], o[8];
+            unpack8(*reinterpret_cast<const uint4*>(p00), a);
+            unpack8(*reinterpret_cast<const uint4*>(p01), b);
+            unpack8(*reinterpret_cast<const uint4*>(p10), c);
+            unpack8(*reinterpret_cast<const uint4*>(p11), d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = w00 * a[j] + w01 * b[j] + w10 * c[j] + w11 * d[j];
+            *reinterpret_cast<uint4*>(dst) = pack8(o);
+        } else {
+            dst[0] = f2bf(w00 * bf2f(p00[0]) + w01 * bf2f(p01[0]) + w10 * bf2f(p10[0]) + w11 * bf2f(p11[0]));
+        }
+    }
+}
+
+// gather-form backward: dx[n, iy, ix, c] = Σ_{oy,ox} wy(oy,iy)·wx(ox,ix)·dy[n, oy, ox, c]
+template <int VEC>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const bf16_raw* __restrict__ dy, bf16_raw* __restrict__ dx,
+                                                           Resize p) {
+    const int CV = p.C / VEC;
+    const long total = (long)p.N * p.Hi * p.Wi * CV;
+    const float inv_ry = p.ry > 0.f ? 1.f / p.ry : 0.f, inv_rx = p.rx > 0.f ? 1.f / p.rx : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long pix = i / CV;
+        const int ix = (int)(pix % p.Wi); pix /= p.Wi;
+        const int iy = (int)(pix % p.Hi);
+        const int n = (int)(pix / p.Hi);
+        // output rows whose source coordinate sy = oy·ry lies in (iy-1, iy+1)
+        int oy_lo, oy_hi, ox_lo, ox_hi;
+        if (p.ry > 0.f) {
+            oy_lo = max(0, (int)ceilf((iy - 1) * inv_ry - 1e-4f));
+            oy_hi = min(p.Ho - 1, (int)floorf((iy + 1) * inv_ry + 1e-4f));
+        } else { oy_lo = 0; oy_hi = p.Ho - 1; }
+        if (p.rx > 0.f) {
+            ox_lo = max(0, (int)ceilf((ix - 1) * inv_rx - 1e-4f));
+            ox_hi = min(p.Wo - 1, (int)floorf((ix + 1) * inv_rx + 1e-4f));
+        } else { ox_lo = 0; ox_hi = p.Wo - 1; }
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        const bf16_raw* base = dy + (long)n * p.Ho * p.Wo * p.C + cv * VEC;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            // replicate the forward's tap selection exactly (including the clamped last row)
+            const float sy = oy * p.ry;
+            const int y0 = min((int)sy, p.Hi - 1), y1 = min(y0 + 1, p.Hi - 1);
+            const float fy = sy - y0;
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - fy;
+            if (y1 == iy) wy += fy;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const float sx = ox * p.rx;
+                const int x0 = min((int)sx, p.Wi - 1), x1 = min(x0 + 1, p.Wi - 1);
+                const float fx = sx - x0;
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - fx;
+                if (x1 == ix) wx += fx;
+                if (wx == 0.f) continue;
+                const float w = wy * wx;
+                const bf16_raw* src = base + ((long)oy * p.Wo + ox) * p.C;
+                if (VEC == 8) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const uint4*>(src), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, f[j], acc[j]);
+                } else {
+                    acc[0] = fmaf(w, bf2f(src[0]), acc[0]);
+                }
+            }
+        }
+        bf16_raw* dst = dx + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cv * VEC;
+        if (VEC == 8) {
+            *reinterpret_cast<uint4*>(dst) = pack8(acc);
+        } else {
+            dst[0] = f2bf(acc[0]);
+        }
+    }
+}
+
+inline int grid_1d(long total, int threads, int cap = 256 * 16) {
+    long b = (total + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+// label_kind: 0 = uint8, 1 = int32, 2 = int64
+DP_EXPORT int dp_softmax_ce_fwd(const void* logits, const void* target, int label_kind, long M, int C,
+                                int ignore_index, float* out2, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C > 1024) return -1;
+    const size_t lds = ((size_t)kCeThreads * C * sizeof(bf16_raw) + 63) / 64 * 64;
+    if (lds > 64 * 1024) return -2;
+    const int grid = grid_1d(M, kCeThreads, 2048);
+#define LAUNCH_FWD(T) hipLaunchKernelGGL(softmax_ce_fwd_kernel<T>, dim3(grid), dim3(kCeThreads), lds, st, \
+                                         (const bf16_raw*)logits, target, M, C, ignore_index, out2)
+    if (label_kind == 0) LAUNCH_FWD(unsigned char);
+    else if (label_kind == 1) LAUNCH_FWD(int);
+    else LAUNCH_FWD(long long);
+#undef LAUNCH_FWD
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_softmax_ce_bwd(const void* logits, const void* target, int label_kind, long M, int C,
+                                int ignore_index, const float* sums, const float* gloss, void* dlogits,
+                                hipStream_t st) {
+    if (M <= 0 || C <= 0 || C > 1024) return -1;
+    const size_t lds = ((size_t)kCeThreads * C * sizeof(bf16_raw) + 63) / 64 * 64;
+    if (lds > 64 * 1024) return -2;
+    const int grid = grid_1d(M, kCeThreads, 2048);
+#define LAUNCH_BWD(T) hipLaunchKernelGGL(softmax_ce_bwd_kernel<T>, dim3(grid), dim3(kCeThreads), lds, st, \
+                                         (const bf16_raw*)logits, target, M, C, ignore_index, sums, gloss, \
+                                         (bf16_raw*)dlogits)
+    if (label_kind == 0) LAUNCH_BWD(unsigned char);
+    else if (label_kind == 1) LAUNCH_BWD(int);
+    else LAUNCH_BWD(long long);
+#undef LAUNCH_BWD
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bilinear_fwd(const void* x, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
+    if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return -1;
+    Resize p{N, C, Hi, Wi, Ho, Wo, Ho > 1 ? (float)(Hi - 1) / (Ho - 1) : 0.f, Wo > 1 ? (float)(Wi - 1) / (Wo - 1) : 0.f};
+    if (C % 8 == 0) {
+        const long total = (long)N * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL(bilinear_fwd_kernel<8>, dim3(grid_1d(total, 256)), dim3(256), 0, st,
+                           (const bf16_raw*)x, (bf16_raw*)y, p);
+    } else {
+        const long total = (long)N * Ho * Wo * C;
+        hipLaunchKernelGGL(bilinear_fwd_kernel<1>, dim3(grid_1d(total, 256)), dim3(256), 0, st,
+                           (const bf16_raw*)x, (bf16_raw*)y, p);
+    }
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bilinear_bwd(const void* dy, void* dx, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                              hipStream_t st) {
+    if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return -1;
+    Resize p{N, C, Hi, Wi, Ho, Wo, Ho > 1 ? (float)(Hi - 1) / (Ho - 1) : 0.f, Wo > 1 ? (float)(Wi - 1) / (Wo - 1) : 0.f};
+    if (C % 8 == 0) {
+        const long total = (long)N * Hi * Wi * (C / 8);
+        hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid_1d(total, 256)), dim3(256), 0, st,
+                           (const bf16_raw*)dy, (bf16_raw*)dx, p);
+    } else {
+        const long total = (long)N * Hi * Wi * C;
+        hipLaunchKernelGGL(bilinear_bwd_kernel<1>, dim3(grid_1d(total, 256)), dim3(256), 0, st,
+                           (const bf16_raw*)dy, (bf16_raw*)dx, p);
+    }
+    return DP_LAUNCH_STATUS();
+}

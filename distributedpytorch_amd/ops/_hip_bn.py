@@ -1,0 +1,134 @@
+"""ctypes bindings for csrc/bn_relu.hip.  Host-side shape/dtype/layout checks happen HERE, before
+any pointer reaches a kernel (a faulting kernel can reset the whole node)."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_long, c_void_p
+
+import torch
+
+from . import _backend as B
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    lib = B.lib()
+    if not _sigs_done:
+        lib.dp_bn_stats.argtypes = [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]
+        lib.dp_bn_apply_stats.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int] + [c_void_p] * 8 + \
+            [c_float, c_float, c_float, c_int, c_void_p]
+        lib.dp_bn_apply_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p,
+                                           c_int, c_void_p]
+        lib.dp_bn_bwd_reduce.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int] + [c_void_p] * 6 + \
+            [c_int, c_void_p]
+        lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int, c_void_p]
+        _sigs_done = True
+    return lib
+
+
+def _check_act(t: torch.Tensor, name: str, like: torch.Tensor | None = None):
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name}: HIP BatchNorm path needs bf16 activations, got {t.dtype}")
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError(f"{name}: expected a channels-last [N,C,H,W] tensor, got strides {t.stride()}")
+    if t.shape[1] % 8 != 0:
+        raise ValueError(f"{name}: channel count {t.shape[1]} must be a multiple of 8")
+    if like is not None and t.shape != like.shape:
+        raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(like.shape)}")
+
+
+def _check_vec(t: torch.Tensor | None, C: int, name: str):
+    if t is None:
+        return
+    if t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous fp32[{C}], got {t.dtype}{tuple(t.shape)}")
+
+
+def _mc(x):
+    n, c, h, w = x.shape
+    return n * h * w, c
+
+
+def as_nhwc(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def stats(x: torch.Tensor):
+    x = as_nhwc(x)
+    _check_act(x, "x")
+    M, C = _mc(x)
+    buf = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    B.check(_lib().dp_bn_stats(B.ptr(x), M, C, B.ptr(buf[0]), B.ptr(buf[1]), B.stream_ptr()), "bn_stats")
+    return buf[0], buf[1]
+
+
+def apply(x, scale, shift, residual, relu):
+    """Affine form (eval / frozen statistics)."""
+    x = as_nhwc(x)
+    _check_act(x, "x")
+    M, C = _mc(x)
+    scale, shift = scale.float().contiguous(), shift.float().contiguous()
+    _check_vec(scale, C, "scale"); _check_vec(shift, C, "shift")
+    if residual is not None:
+        residual = as_nhwc(residual)
+        _check_act(residual, "residual", x)
+    y = torch.empty_like(x)
+    B.check(_lib().dp_bn_apply_affine(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(scale), B.ptr(shift),
+                                      int(relu), B.stream_ptr()), "bn_apply_affine")
+    return y
+
+
+def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var, count, eps, momentum, relu):
+    """Training form: finalises mean/invstd/running stats inside the apply kernel.
+    Returns (y, mean, invstd)."""
+    x = as_nhwc(x)
+    _check_act(x, "x")
+    M, C = _mc(x)
+    for t, nm in ((s, "sum"), (ss, "sqsum"), (weight, "weight"), (bias, "bias"),
+                  (running_mean, "running_mean"), (running_var, "running_var")):
+        _check_vec(t, C, nm)
+    if residual is not None:
+        residual = as_nhwc(residual)
+        _check_act(residual, "residual", x)
+    y = torch.empty_like(x)
+    mi = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    B.check(_lib().dp_bn_apply_stats(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(s), B.ptr(ss),
+                                     B.ptr(weight), B.ptr(bias), B.ptr(mi[0]), B.ptr(mi[1]),
+                                     B.ptr(running_mean), B.ptr(running_var), float(count), float(eps),
+                                     float(momentum), int(relu), B.stream_ptr()), "bn_apply_stats")
+    return y, mi[0], mi[1]
+
+
+def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode):
+    dy = as_nhwc(dy)
+    _check_act(x, "x"); _check_act(dy, "dy", x)
+    M, C = _mc(x)
+    if mask_mode == 1:
+        _check_act(y, "y", x)
+    for t, nm in ((mean, "mean"), (invstd, "invstd"), (weight, "weight"), (bias, "bias")):
+        _check_vec(t, C, nm)
+    buf = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    B.check(_lib().dp_bn_bwd_reduce(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), M, C,
+                                    B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
+                                    B.ptr(buf[0]), B.ptr(buf[1]), int(mask_mode), B.stream_ptr()), "bn_bwd_reduce")
+    return buf[0], buf[1]
+
+
+def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres):
+    dy = as_nhwc(dy)
+    _check_act(x, "x"); _check_act(dy, "dy", x)
+    M, C = _mc(x)
+    if mask_mode == 1:
+        _check_act(y, "y", x)
+    for t, nm in ((mean, "mean"), (invstd, "invstd"), (weight, "weight"), (bias, "bias"),
+                  (sdy, "sdy"), (sdyx, "sdyx")):
+        _check_vec(t, C, nm)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if need_dres else None
+    B.check(_lib().dp_bn_bwd_apply(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), B.ptr(dx),
+                                   B.ptr(dres), M, C, B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
+                                   B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.stream_ptr()),
+            "bn_bwd_apply")
+    return dx, dres

@@ -1,0 +1,210 @@
+"""Autograd wrapper + ctypes bindings for the implicit-GEMM conv kernels (csrc/conv_igemm.hip,
+csrc/conv_wgrad.hip, csrc/depthwise.hip).
+
+forward   y  = igemm(x, w)                                   [K1]
+backward  dx = igemm(dy, wT, pad' = dil·(k-1) - pad, sdiv = stride)   [K2]  (same kernel)
+          dw = wgrad(dy, x)   fp32, KRSC                       [K3]
+
+All shape / dtype / layout / alignment checks are done here on the host before a pointer reaches
+a kernel.
+"""
+from __future__ import annotations
+
+from ctypes import c_int, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+from . import _backend as B
+from ._hip_bn import as_nhwc
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    lib = B.lib()
+    if not _sigs_done:
+        V, I = c_void_p, c_int
+        lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 17 + [V]
+        lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
+        lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
+        lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
+        lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
+        lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 10 + [V]
+        _sigs_done = True
+    return lib
+
+
+def _out_size(n, k, s, p, d):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def _round8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
+          pad: Tuple[int, int], dil: Tuple[int, int], bias: Optional[torch.Tensor] = None,
+          stats: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """Raw kernel call.  ``x`` [N,Cin,Hi,Wi] channels-last bf16; ``w_krsc`` logical [Cout,Cin,R,S]
+    stored channels-last (memory [Cout][R][S][Cin]).  Returns [N,Cout,Ho,Wo] channels-last bf16."""
+    n, cin, hi, wi = x.shape
+    cout, cin_w, r, s = w_krsc.shape
+    if x.dtype != torch.bfloat16 or w_krsc.dtype != torch.bfloat16:
+        raise TypeError("igemm: bf16 operands required")
+    if cin != cin_w or cin % 8:
+        raise ValueError(f"igemm: Cin mismatch or not a multiple of 8 ({cin} vs {cin_w})")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("igemm: x must be channels-last")
+    if not (w_krsc.permute(0, 2, 3, 1).is_contiguous()):
+        raise ValueError("igemm: weights must be stored [Cout][R][S][Cin]")
+    ho, wo = out_hw
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != cout):
+        raise ValueError("igemm: bias must be fp32[Cout]")
+    if stats is not None and (stats.dtype != torch.float32 or stats.numel() != 2 * cout):
+        raise ValueError("igemm: stats must be fp32[2,Cout]")
+    B.check(_lib().dp_conv_igemm(B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(bias), B.ptr(stats), n, hi, wi, cin,
+                                 ho, wo, cout, r, s, smul, sdiv, pad[0], pad[1], dil[0], dil[1], cout, tile,
+                                 B.stream_ptr()), "conv_igemm")
+    return y
+
+
+def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
+    """wT[c][R-1-r][S-1-s][k] = w[k][r][s][c]; returns logical [Cin,Cout,R,S] stored channels-last."""
+    cout, cin, r, s = w_krsc.shape
+    wt = torch.empty((cin, cout, r, s), dtype=w_krsc.dtype, device=w_krsc.device,
+                     memory_format=torch.channels_last)
+    if r == 1 and s == 1:
+        # 1×1: a plain 2-D transpose
+        wt.view(cin, cout).copy_(w_krsc.view(cout, cin).t())
+        return wt
+    B.check(_lib().dp_weight_transpose(B.ptr(w_krsc), B.ptr(wt), cout, r, s, cin, B.stream_ptr()),
+            "weight_transpose")
+    return wt
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil) -> torch.Tensor:
+    """dw fp32, logical [Cout,Cin,R,S] stored channels-last (KRSC)."""
+    cout, cin, r, s = wshape
+    n, _, hi, wi = x.shape
+    _, _, ho, wo = dy.shape
+    dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
+                     memory_format=torch.channels_last).zero_()
+    B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
+                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 0, 0, B.stream_ptr()),
+            "conv_wgrad")
+    return dw
+
+
+class _ConvIGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation):
+        cout, cin, r, s = weight.shape
+        n, _, hi, wi = x.shape
+        ho = _out_size(hi, r, stride[0], padding[0], dilation[0])
+        wo = _out_size(wi, s, stride[1], padding[1], dilation[1])
+        if stride[0] != stride[1]:
+            raise NotImplementedError("anisotropic stride")
+        x = as_nhwc(x)
+        cin_p, cout_p = _round8(cin), _round8(cout)
+        w_used = w_lowp
+        if cin_p != cin or cout_p != cout:
+            # rare shapes (RGB stem, 21-class classifier): zero-pad channels to the 16-byte granule
+            from . import _hip_misc
+            w_used = torch.empty((cout_p, cin_p, r, s), dtype=w_lowp.dtype, device=x.device,
+                                 memory_format=torch.channels_last).zero_()
+            w_used[:cout, :cin] = w_lowp
+            if cin_p != cin:
+                x = _hip_misc.pad_channels(x, cin_p)
+        b32 = None
+        if bias is not None:
+            b32 = torch.zeros(cout_p, dtype=torch.float32, device=x.device)
+            b32[:cout] = bias.detach().float()
+        y = igemm(x, w_used, (ho, wo), stride[0], 1, padding, dilation, b32)
+        ctx.save_for_backward(x, w_used)
+        ctx.geom = (stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p)
+        ctx.has_bias = bias is not None
+        if cout_p != cout:
+            y = y[:, :cout]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_used = ctx.saved_tensors
+        stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p = ctx.geom
+        if cout_p != cout:
+            dyp = torch.empty((dy.shape[0], cout_p, dy.shape[2], dy.shape[3]), dtype=dy.dtype, device=dy.device,
+                              memory_format=torch.channels_last).zero_()
+            dyp[:, :cout] = dy
+            dy = dyp
+        dy = as_nhwc(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight_transpose(w_used)
+            pad_t = (dilation[0] * (r - 1) - padding[0], dilation[1] * (s - 1) - padding[1])
+            dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation)
+            if cin_p != cin:
+                dx = dx[:, :cin]
+        if ctx.needs_input_grad[1]:
+            dw = wgrad(dy, x, (cout_p, cin_p, r, s), stride, padding, dilation)
+            if cout_p != cout or cin_p != cin:
+                dw = dw[:cout, :cin]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum(dim=(0, 2, 3))[:cout]
+        return dx, dw, db, None, None, None, None
+
+
+class _DepthwiseConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, w_lowp, stride, padding, dilation):
+        c = x.shape[1]
+        n, _, hi, wi = x.shape
+        if weight.shape[2:] != (3, 3) or c % 8:
+            raise NotImplementedError("depthwise kernel: 3×3, C % 8 == 0")
+        x = as_nhwc(x)
+        ho = _out_size(hi, 3, stride[0], padding[0], dilation[0])
+        wo = _out_size(wi, 3, stride[1], padding[1], dilation[1])
+        w9 = w_lowp.reshape(c, 9).t().contiguous()  # [9][C]: tap-major so 8 channels are one 16-B load
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        B.check(_lib().dp_dwconv_fwd(B.ptr(x), B.ptr(w9), B.ptr(y), n, c, hi, wi, ho, wo, stride[0], padding[0],
+                                     padding[1], dilation[0], B.stream_ptr()), "dwconv_fwd")
+        ctx.save_for_backward(x, w9)
+        ctx.geom = (stride, padding, dilation, (hi, wi), (ho, wo))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w9 = ctx.saved_tensors
+        stride, padding, dilation, (hi, wi), (ho, wo) = ctx.geom
+        n, c = x.shape[:2]
+        dy = as_nhwc(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            B.check(_lib().dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), n, c, hi, wi, ho, wo, stride[0],
+                                              padding[0], padding[1], dilation[0], B.stream_ptr()), "dwconv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw9 = torch.zeros((9, c), dtype=torch.float32, device=x.device)
+            B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo, stride[0],
+                                                padding[0], padding[1], dilation[0], B.stream_ptr()),
+                    "dwconv_bwd_weight")
+            dw = dw9.t().reshape(c, 1, 3, 3)
+        return dx, dw, None, None, None, None
+
+
+def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp):
+    if x.dtype != torch.bfloat16:
+        raise TypeError(f"HIP conv path needs bf16 activations, got {x.dtype}")
+    if w_lowp is None:
+        w_lowp = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if groups == 1:
+        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation)
+    if groups == x.shape[1] == weight.shape[0] and weight.shape[1] == 1:
+        if bias is not None:
+            raise NotImplementedError("depthwise bias")
+        if dilation[0] != dilation[1] or stride[0] != stride[1]:
+            raise NotImplementedError("anisotropic depthwise")
+        return _DepthwiseConv.apply(x, weight, w_lowp, stride, padding, dilation)
+    raise NotImplementedError(f"grouped convolution with groups={groups} (only dense and depthwise)")

@@ -1,0 +1,215 @@
+"""ctypes bindings for csrc/loss_upsample.hip and csrc/misc.hip with host-side validation."""
+from __future__ import annotations
+
+from ctypes import c_float, c_int, c_long, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+from . import _backend as B
+from ._hip_bn import as_nhwc
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    lib = B.lib()
+    if not _sigs_done:
+        V, I, L, F = c_void_p, c_int, c_long, c_float
+        lib.dp_softmax_ce_fwd.argtypes = [V, V, I, L, I, I, V, V]
+        lib.dp_softmax_ce_bwd.argtypes = [V, V, I, L, I, I, V, V, V, V]
+        lib.dp_bilinear_fwd.argtypes = [V, V, I, I, I, I, I, I, V]
+        lib.dp_bilinear_bwd.argtypes = [V, V, I, I, I, I, I, I, V]
+        lib.dp_sgd_flat.argtypes = [V, V, V, V, L, F, F, F, F, I, I, V]
+        lib.dp_scale_bf16.argtypes = [V, L, V, V]
+        lib.dp_maxpool3x3s2_fwd.argtypes = [V, V, I, I, I, I, I, I, V]
+        lib.dp_maxpool3x3s2_bwd.argtypes = [V, V, V, V, I, I, I, I, I, I, V]
+        lib.dp_gap_fwd.argtypes = [V, V, I, I, I, V]
+        lib.dp_gap_bwd.argtypes = [V, V, I, I, I, V]
+        lib.dp_affine_augment.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V, V, V]
+        lib.dp_confusion.argtypes = [V, I, V, I, L, I, I, I, V, V]
+        lib.dp_pad_channels.argtypes = [V, V, L, I, I, V]
+        _sigs_done = True
+    return lib
+
+
+def _req_bf16_nhwc(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name}: HIP path needs bf16, got {t.dtype}")
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected [N,C,H,W]")
+    t = as_nhwc(t)
+    if t.data_ptr() % 16:
+        raise ValueError(f"{name}: data pointer must be 16-byte aligned")
+    return t
+
+
+_LABEL_KIND = {torch.uint8: 0, torch.int32: 1, torch.int64: 2}
+
+
+def _label(target: torch.Tensor, shape) -> Tuple[torch.Tensor, int]:
+    if target.dtype not in _LABEL_KIND:
+        target = target.long()
+    if tuple(target.shape) != tuple(shape):
+        raise ValueError(f"target shape {tuple(target.shape)} != {tuple(shape)}")
+    return target.contiguous(), _LABEL_KIND[target.dtype]
+
+
+# ------------------------------------------------------------------ softmax CE
+def softmax_ce_fwd(logits: torch.Tensor, target: torch.Tensor, ignore_index: int):
+    logits = _req_bf16_nhwc(logits, "logits")
+    n, c, h, w = logits.shape
+    target, kind = _label(target, (n, h, w))
+    sums = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    B.check(_lib().dp_softmax_ce_fwd(B.ptr(logits), B.ptr(target), kind, n * h * w, c, int(ignore_index),
+                                     B.ptr(sums), B.stream_ptr()), "softmax_ce_fwd")
+    loss = sums[0] / sums[1].clamp_min(1.0)
+    return loss, sums, logits, target
+
+
+def softmax_ce_bwd(logits, target, ignore_index, sums, gloss):
+    n, c, h, w = logits.shape
+    kind = _LABEL_KIND[target.dtype]
+    g = gloss.detach().reshape(1).float().contiguous()
+    dlogits = torch.empty_like(logits)
+    B.check(_lib().dp_softmax_ce_bwd(B.ptr(logits), B.ptr(target), kind, n * h * w, c, int(ignore_index),
+                                     B.ptr(sums), B.ptr(g), B.ptr(dlogits), B.stream_ptr()), "softmax_ce_bwd")
+    return dlogits
+
+
+# ------------------------------------------------------------------ bilinear
+def bilinear_fwd(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    x = _req_bf16_nhwc(x, "x")
+    n, c, hi, wi = x.shape
+    ho, wo = size
+    y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_bilinear_fwd(B.ptr(x), B.ptr(y), n, c, hi, wi, ho, wo, B.stream_ptr()), "bilinear_fwd")
+    return y
+
+
+def bilinear_bwd(dy: torch.Tensor, in_size: Tuple[int, int]) -> torch.Tensor:
+    dy = _req_bf16_nhwc(dy, "dy")
+    n, c, ho, wo = dy.shape
+    hi, wi = in_size
+    dx = torch.empty((n, c, hi, wi), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_bilinear_bwd(B.ptr(dy), B.ptr(dx), n, c, hi, wi, ho, wo, B.stream_ptr()), "bilinear_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ pooling
+def maxpool3x3s2_fwd(x):
+    x = _req_bf16_nhwc(x, "x")
+    n, c, hi, wi = x.shape
+    if c % 8:
+        raise ValueError("max-pool kernel needs C % 8 == 0")
+    ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+    y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_maxpool3x3s2_fwd(B.ptr(x), B.ptr(y), n, c, hi, wi, ho, wo, B.stream_ptr()), "maxpool_fwd")
+    return y
+
+
+def maxpool3x3s2_bwd(dy, x, y):
+    dy = _req_bf16_nhwc(dy, "dy")
+    n, c, hi, wi = x.shape
+    ho, wo = y.shape[2:]
+    if dy.shape != y.shape:
+        raise ValueError("dy/y shape mismatch")
+    dx = torch.empty_like(x)
+    B.check(_lib().dp_maxpool3x3s2_bwd(B.ptr(dy), B.ptr(x), B.ptr(y), B.ptr(dx), n, c, hi, wi, ho, wo,
+                                       B.stream_ptr()), "maxpool_bwd")
+    return dx
+
+
+def global_avgpool_fwd(x):
+    x = _req_bf16_nhwc(x, "x")
+    n, c, h, w = x.shape
+    if c % 8:
+        raise ValueError("global-avg-pool kernel needs C % 8 == 0")
+    y = torch.empty((n, c, 1, 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_gap_fwd(B.ptr(x), B.ptr(y), n, c, h * w, B.stream_ptr()), "gap_fwd")
+    return y
+
+
+def global_avgpool_bwd(dy, shape):
+    n, c, h, w = shape
+    dy = dy.reshape(n, c).contiguous()
+    if dy.dtype != torch.bfloat16:
+        raise TypeError("gap_bwd needs bf16")
+    dx = torch.empty(shape, dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_gap_bwd(B.ptr(dy), B.ptr(dx), n, c, h * w, B.stream_ptr()), "gap_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ SGD / scale
+def sgd_flat(p, g, m, p_lowp, lr, momentum, weight_decay, grad_scale, zero_grad, first_step):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m")):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"sgd_flat: {nm} must be contiguous fp32")
+    if p_lowp is not None and (p_lowp.dtype != torch.bfloat16 or p_lowp.numel() != p.numel()):
+        raise TypeError("sgd_flat: low-precision copy must be bf16 with the same numel")
+    B.check(_lib().dp_sgd_flat(B.ptr(p), B.ptr(g), B.ptr(m), B.ptr(p_lowp), p.numel(), float(lr), float(momentum),
+                               float(weight_decay), float(grad_scale), int(zero_grad), int(first_step),
+                               B.stream_ptr()), "sgd_flat")
+
+
+def scale_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """x *= s (device scalar), in place, bf16."""
+    s = s.detach().reshape(1).float().contiguous()
+    B.check(_lib().dp_scale_bf16(B.ptr(x), x.numel(), B.ptr(s), B.stream_ptr()), "scale_bf16")
+    return x
+
+
+# ------------------------------------------------------------------ augmentation
+def affine_augment(img_u8, lab_u8, mats, out_size, mean, std, out_dtype, pad_to: int = 3):
+    if out_dtype != torch.bfloat16:
+        raise TypeError("HIP augmentation writes bf16")
+    img_u8 = img_u8.contiguous()
+    bsz, hi, wi, _ = img_u8.shape
+    ho, wo = out_size
+    mats = mats.to(device=img_u8.device, dtype=torch.float32).contiguous()
+    if lab_u8 is not None:
+        if lab_u8.dtype != torch.uint8 or tuple(lab_u8.shape) != (bsz, hi, wi):
+            raise ValueError("label must be uint8 [B,H,W]")
+        lab_u8 = lab_u8.contiguous()
+    cout = max(3, pad_to)
+    out = torch.empty((bsz, ho, wo, cout), dtype=torch.bfloat16, device=img_u8.device)
+    out_lab = torch.empty((bsz, ho, wo), dtype=torch.uint8, device=img_u8.device) if lab_u8 is not None else None
+    import ctypes
+    mean_c = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    std_c = (ctypes.c_float * 3)(*[float(v) for v in std])
+    B.check(_lib().dp_affine_augment(B.ptr(img_u8), B.ptr(lab_u8), B.ptr(mats), B.ptr(out), B.ptr(out_lab),
+                                     bsz, hi, wi, ho, wo, cout, mean_c, std_c, B.stream_ptr()), "affine_augment")
+    return out.permute(0, 3, 1, 2), out_lab  # [B,C,H,W] view over NHWC memory (channels-last)
+
+
+# ------------------------------------------------------------------ confusion matrix
+def confusion(pred, target, num_classes, ignore_index, out):
+    if out.dtype != torch.int64 or out.numel() != num_classes * num_classes or not out.is_contiguous():
+        raise ValueError("confusion: out must be contiguous int64 [K,K]")
+    if target.dtype not in (torch.uint8, torch.int64):
+        target = target.long()
+    target = target.contiguous()
+    tk = 0 if target.dtype == torch.uint8 else 2
+    if pred.dim() == 4:
+        pred = _req_bf16_nhwc(pred, "logits")
+        n, c, h, w = pred.shape
+        m, kind = n * h * w, 0
+    else:
+        if pred.dtype not in (torch.uint8, torch.int64):
+            pred = pred.long()
+        pred = pred.contiguous()
+        c, m = 0, pred.numel()
+        kind = 1 if pred.dtype == torch.uint8 else 2
+    if target.numel() != m:
+        raise ValueError("confusion: pred/target size mismatch")
+    B.check(_lib().dp_confusion(B.ptr(pred), kind, B.ptr(target), tk, m, c, num_classes, int(ignore_index),
+                                B.ptr(out), B.stream_ptr()), "confusion")
+
+
+def pad_channels(x: torch.Tensor, cout: int) -> torch.Tensor:
+    x = _req_bf16_nhwc(x, "x")
+    n, c, h, w = x.shape
+    y = torch.empty((n, cout, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_pad_channels(B.ptr(x), B.ptr(y), n * h * w, c, cout, B.stream_ptr()), "pad_channels")
+    return y

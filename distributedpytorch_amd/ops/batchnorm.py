@@ -62,32 +62,11 @@ def _t_bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, rel
     return dx.to(x.dtype), dres
 
 
-def _stats(x):
-    if B.use_hip(x):
-        from . import _hip_bn
-        return _hip_bn.stats(x)
-    return _t_stats(x)
-
-
-def _apply(x, scale, shift, residual, relu):
+def _apply_affine(x, scale, shift, residual, relu):
     if B.use_hip(x):
         from . import _hip_bn
         return _hip_bn.apply(x, scale, shift, residual, relu)
     return _t_apply(x, scale, shift, residual, relu)
-
-
-def _bwd_reduce(dy, x, y, mean, invstd, relu):
-    if B.use_hip(x):
-        from . import _hip_bn
-        return _hip_bn.bwd_reduce(dy, x, y, mean, invstd, relu)
-    return _t_bwd_reduce(dy, x, y, mean, invstd, relu)
-
-
-def _bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres):
-    if B.use_hip(x):
-        from . import _hip_bn
-        return _hip_bn.bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres)
-    return _t_bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres)
 
 
 def _group_active(group) -> bool:
@@ -103,7 +82,13 @@ class _BatchNormActTrain(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group):
         C = x.shape[1]
         local_count = x.numel() // C
-        s, ss = _stats(x)
+        hip = B.use_hip(x)
+        if hip:
+            from . import _hip_bn
+            x = _hip_bn.as_nhwc(x)
+            s, ss = _hip_bn.stats(x)
+        else:
+            s, ss = _t_stats(x)
         count = float(local_count)
         sync = _group_active(group)
         pg = None if group is True else group
@@ -111,49 +96,66 @@ class _BatchNormActTrain(torch.autograd.Function):
             # C4: one fused message [Σx | Σx² | count] per layer (2C+1 floats).
             packed = torch.cat([s, ss, s.new_tensor([count])])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
-            s, ss = packed[:C], packed[C:2 * C]
+            s, ss = packed[:C].contiguous(), packed[C:2 * C].contiguous()
             if x.is_cuda:
                 # no device->host sync on the hot path: the sampler drops the ragged tail, so every
                 # rank contributes the same B·H·W (checked under DPAMD_DEBUG in parallel.debug)
                 count = float(local_count * dist.get_world_size(pg))
             else:
                 count = float(packed[2 * C].item())
-        mean = s / count
-        var = (ss / count - mean * mean).clamp_min_(0.0)
-        invstd = torch.rsqrt(var + eps)
-        if running_mean is not None:
-            with torch.no_grad():
-                unbiased = var * (count / max(count - 1.0, 1.0))
-                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
-        w = weight.float() if weight is not None else torch.ones_like(mean)
-        b = bias.float() if bias is not None else torch.zeros_like(mean)
-        scale = w * invstd
-        shift = b - mean * scale
-        y = _apply(x, scale, shift, residual, relu)
-        ctx.save_for_backward(x, y if relu else None, w, mean, invstd)
-        ctx.relu, ctx.count, ctx.sync, ctx.pg = relu, count, sync, pg
+        if hip:
+            # the apply kernel finalises mean / invstd / running statistics itself (block 0)
+            w = weight.detach().float().contiguous() if weight is not None else None
+            b = bias.detach().float().contiguous() if bias is not None else None
+            y, mean, invstd = _hip_bn.apply_from_stats(x, s, ss, w, b, residual, running_mean, running_var,
+                                                       count, eps, momentum, relu)
+            mask_mode = 0 if not relu else (1 if residual is not None else 2)
+            ctx.save_for_backward(x, y if mask_mode == 1 else None, w, b, mean, invstd)
+            ctx.mask_mode = mask_mode
+        else:
+            mean = s / count
+            var = (ss / count - mean * mean).clamp_min_(0.0)
+            invstd = torch.rsqrt(var + eps)
+            if running_mean is not None:
+                with torch.no_grad():
+                    unbiased = var * (count / max(count - 1.0, 1.0))
+                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+            w = weight.detach().float() if weight is not None else torch.ones_like(mean)
+            b = bias.detach().float() if bias is not None else torch.zeros_like(mean)
+            scale = w * invstd
+            shift = b - mean * scale
+            y = _t_apply(x, scale, shift, residual, relu)
+            ctx.save_for_backward(x, y if relu else None, w, b, mean, invstd)
+        ctx.hip, ctx.relu, ctx.count, ctx.sync, ctx.pg = hip, relu, count, sync, pg
         ctx.has_res = residual is not None
         ctx.has_affine = weight is not None
+        ctx.wdtype = weight.dtype if weight is not None else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, w, mean, invstd = ctx.saved_tensors
-        if not dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
-            dy = dy.contiguous(memory_format=torch.channels_last)
+        x, y, w, b, mean, invstd = ctx.saved_tensors
         C = x.shape[1]
-        sdy, sdyx = _bwd_reduce(dy, x, y, mean, invstd, ctx.relu)
+        need_dres = ctx.has_res and ctx.needs_input_grad[3]
+        if ctx.hip:
+            from . import _hip_bn
+            sdy, sdyx = _hip_bn.bwd_reduce(dy, x, y, mean, invstd, w, b, ctx.mask_mode)
+        else:
+            sdy, sdyx = _t_bwd_reduce(dy, x, y, mean, invstd, ctx.relu)
         g_sdy, g_sdyx = sdy, sdyx
         if ctx.sync:
             packed = torch.cat([sdy, sdyx])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.pg)
-            g_sdy, g_sdyx = packed[:C], packed[C:]
-        need_dres = ctx.has_res and ctx.needs_input_grad[3]
-        dx, dres = _bwd_apply(dy, x, y, mean, invstd, w, g_sdy, g_sdyx, ctx.count, ctx.relu, need_dres)
+            g_sdy, g_sdyx = packed[:C].contiguous(), packed[C:].contiguous()
+        if ctx.hip:
+            dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
+                                         ctx.mask_mode, need_dres)
+        else:
+            dx, dres = _t_bwd_apply(dy, x, y, mean, invstd, w, g_sdy, g_sdyx, ctx.count, ctx.relu, need_dres)
         # affine grads are *local* sums: DDP's gradient all-reduce averages them like any other param
-        dweight = sdyx.to(w.dtype) if ctx.has_affine else None
-        dbias = sdy.to(w.dtype) if ctx.has_affine else None
+        dweight = sdyx.to(ctx.wdtype) if ctx.has_affine else None
+        dbias = sdy.to(ctx.wdtype) if ctx.has_affine else None
         return dx, dweight, dbias, dres, None, None, None, None, None, None
 
 
@@ -162,7 +164,7 @@ class _BatchNormActFrozen(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale, shift, residual, relu):
-        y = _apply(x, scale, shift, residual, relu)
+        y = _apply_affine(x, scale, shift, residual, relu)
         ctx.save_for_backward(y if relu else None, scale)
         ctx.relu, ctx.has_res = relu, residual is not None
         return y
@@ -170,6 +172,16 @@ class _BatchNormActFrozen(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         y, scale = ctx.saved_tensors
+        need_dres = ctx.has_res and ctx.needs_input_grad[3]
+        if B.use_hip(dy):
+            from . import _hip_bn
+            # frozen statistics: dx = scale·dy' — the bwd_apply kernel with (weight=scale, invstd=1,
+            # mean=0, no batch terms); the ReLU mask comes from the saved output
+            ones, zeros = torch.ones_like(scale), torch.zeros_like(scale)
+            ref = y if y is not None else _hip_bn.as_nhwc(dy)
+            dx, dres = _hip_bn.bwd_apply(dy, ref, y, zeros, ones, scale.contiguous(), zeros, None, None, 1.0,
+                                         1 if ctx.relu else 0, need_dres)
+            return dx, None, None, dres, None
         dyf = dy.float()
         if ctx.relu:
             dyf = dyf * (y > 0)
@@ -197,7 +209,7 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
     shift = (bias.float() if bias is not None else 0.0) - running_mean.float() * scale
     if torch.is_grad_enabled() and x.requires_grad:
         return _BatchNormActFrozen.apply(x, scale, shift, residual, relu)
-    return _apply(x, scale, shift, residual, relu)
+    return _apply_affine(x, scale, shift, residual, relu)
 
 
 class BatchNorm2d(nn.Module):

@@ -2,8 +2,10 @@
 
 The reference computes its loss with ``criterion.forward(output, gts)``
 (`/root/reference/train_pascal.py:199`); the north star replaces the binary loss by a 21-class
-softmax CE with the VOC void label 255 ignored.  GPU path: ONE kernel pass computes the per-pixel
-loss, the valid-pixel count and ``dlogits``; backward only scales the stored ``dlogits``.
+softmax CE with the VOC void label 255 ignored.  GPU path: the forward kernel reduces the per-pixel
+loss and the valid-pixel count on device; the backward kernel recomputes the softmax from the
+logits and writes ``dlogits`` already scaled by ``grad/count`` (3 passes over the logits in total,
+nothing but the logits held between forward and backward).
 """
 from __future__ import annotations
 
@@ -18,15 +20,16 @@ class _SoftmaxCEHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
         from . import _hip_misc
-        loss, dlogits = _hip_misc.softmax_ce_fwd(logits, target, ignore_index, logits.requires_grad)
-        ctx.save_for_backward(dlogits)
+        loss, sums, logits_nhwc, target_c = _hip_misc.softmax_ce_fwd(logits, target, ignore_index)
+        ctx.save_for_backward(logits_nhwc, target_c, sums)
+        ctx.ignore_index = ignore_index
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        (dlogits,) = ctx.saved_tensors
         from . import _hip_misc
-        return _hip_misc.scale_(dlogits, gloss), None, None
+        logits, target, sums = ctx.saved_tensors
+        return _hip_misc.softmax_ce_bwd(logits, target, ctx.ignore_index, sums, gloss), None, None
 
 
 def softmax_cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = 255) -> torch.Tensor:

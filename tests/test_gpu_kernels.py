@@ -1,0 +1,310 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op
+(SURVEY.md §4 item 2).  Run on an MI355X: ``pytest -m gpu``.
+
+Inputs are rounded to bf16 first so the comparison isolates the kernel's arithmetic (fp32
+accumulation, bf16 output rounding) from input quantisation."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from distributedpytorch_amd import ops
+from distributedpytorch_amd.ops import _backend as B
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _nhwc(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def test_library_loaded():
+    assert B.lib_built(), "libdpamd_hip.so missing: run python -m distributedpytorch_amd.csrc.build"
+    B.lib()
+
+
+# ----------------------------------------------------------------------------- conv
+CONV_CASES = [
+    # n, cin, cout, h, w, k, stride, pad, dil
+    (2, 64, 128, 33, 33, 1, 1, 0, 1),
+    (2, 64, 64, 17, 19, 3, 1, 1, 1),
+    (1, 128, 256, 33, 33, 3, 1, 2, 2),
+    (1, 256, 256, 33, 33, 3, 1, 6, 6),
+    (1, 64, 128, 33, 33, 3, 1, 12, 12),
+    (1, 64, 64, 33, 33, 3, 1, 18, 18),
+    (2, 64, 128, 65, 65, 3, 2, 1, 1),
+    (2, 128, 256, 33, 35, 1, 2, 0, 1),
+    (2, 304, 256, 17, 17, 3, 1, 1, 1),     # Cin not a multiple of 64 (decoder concat)
+    (2, 256, 48, 19, 19, 1, 1, 0, 1),      # Cout = 48
+    (2, 256, 21, 19, 19, 1, 1, 0, 1),      # classifier: Cout = 21 (padded internally)
+    (2, 3, 64, 65, 65, 7, 2, 3, 1),        # RGB stem
+    (3, 2048, 256, 9, 9, 3, 1, 6, 6),      # deep K, halo larger than the map
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case):
+    n, cin, cout, h, w, k, stride, pad, dil = case
+    torch.manual_seed(0)
+    x = _bf(torch.randn(n, cin, h, w, device=DEV))
+    wt = _bf(torch.randn(cout, cin, k, k, device=DEV) / math.sqrt(cin * k * k))
+    bias = torch.randn(cout, device=DEV) if cout == 21 else None
+    # reference on the CPU in fp32: independent of MIOpen
+    xr = x.float().cpu().requires_grad_(True)
+    wr = wt.float().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None if bias is None else bias.cpu(), stride, pad, dil)
+    gy = _bf(torch.randn_like(yr)).to(DEV)
+    yr.backward(gy.float().cpu())
+
+    xh = _nhwc(x).requires_grad_(True)
+    wh = wt.float().requires_grad_(True)
+    yh = ops.conv2d(xh, wh, bias, stride, pad, dil)
+    assert yh.shape == yr.shape and yh.dtype == torch.bfloat16
+    assert _rel(yh, yr) < 1.5e-2
+    yh.backward(_nhwc(gy))
+    if cin != 3:
+        assert _rel(xh.grad, xr.grad) < 1.5e-2
+    assert _rel(wh.grad, wr.grad) < 1.5e-2
+
+
+def test_conv_identity_asymmetric():
+    """A = I check with an asymmetric B: catches swapped row/col maps of the MFMA C layout."""
+    cin = cout = 64
+    x = torch.zeros(1, cin, 8, 16, device=DEV)
+    for i in range(cin):
+        x[0, i, i // 16, i % 16] = 1.0   # pixel p has a one in channel p (p < 64)
+    w = torch.arange(cout * cin, device=DEV, dtype=torch.float32).view(cout, cin, 1, 1) % 251 / 64.0
+    y = ops.conv2d(_nhwc(_bf(x)), _bf(w).float(), None, 1, 0, 1)
+    ref = F.conv2d(_bf(x).float().cpu(), _bf(w).float().cpu())
+    assert torch.allclose(y.float().cpu(), ref, atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
+def test_depthwise(stride, dil):
+    torch.manual_seed(1)
+    n, c, h, w = 2, 72, 33, 31
+    x = _bf(torch.randn(n, c, h, w, device=DEV))
+    wt = _bf(torch.randn(c, 1, 3, 3, device=DEV) / 3)
+    xr, wr = x.float().cpu().requires_grad_(True), wt.float().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, dil, dil, groups=c)
+    gy = _bf(torch.randn_like(yr)).to(DEV)
+    yr.backward(gy.float().cpu())
+    xh, wh = _nhwc(x).requires_grad_(True), wt.float().requires_grad_(True)
+    yh = ops.conv2d(xh, wh, None, stride, dil, dil, groups=c)
+    assert _rel(yh, yr) < 1.5e-2
+    yh.backward(_nhwc(gy))
+    assert _rel(xh.grad, xr.grad) < 1.5e-2
+    assert _rel(wh.grad, wr.grad) < 1.5e-2
+
+
+# ----------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize("shape", [(2, 64, 33, 33), (3, 48, 17, 9), (2, 2048, 9, 9), (2, 728, 17, 17),
+                                   (1, 4096, 5, 5)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_batchnorm_train(shape, relu, res):
+    torch.manual_seed(2)
+    n, c, h, w = shape
+    x = _bf(torch.randn(shape, device=DEV) * 2 + 0.5)
+    r = _bf(torch.randn(shape, device=DEV)) if res else None
+    wt = torch.rand(c, device=DEV) + 0.5
+    bs = torch.randn(c, device=DEV) * 0.1
+    gy = _bf(torch.randn(shape, device=DEV))
+
+    def run(dev, xin, rin):
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        xi = xin.to(dev).clone().requires_grad_(True)
+        ri = rin.to(dev).clone().requires_grad_(True) if rin is not None else None
+        wi, bi = wt.to(dev).clone().requires_grad_(True), bs.to(dev).clone().requires_grad_(True)
+        y = ops.batch_norm_act(xi, wi, bi, rm, rv, True, 0.1, 1e-5, relu, ri)
+        y.backward(gy.to(dev).to(y.dtype))
+        return y, xi.grad, wi.grad, bi.grad, (ri.grad if ri is not None else None), rm, rv
+
+    # reference: the plain tensor-math path of the same Function, fp32 on the CPU
+    ref = run("cpu", x.float(), r.float() if res else None)
+    got = run(DEV, _nhwc(x), _nhwc(r) if res else None)
+    assert _rel(got[0], ref[0]) < 2e-2, "y"
+    assert _rel(got[1], ref[1]) < 3e-2, "dx"
+    assert _rel(got[2], ref[2]) < 2e-2, "dweight"
+    assert _rel(got[3], ref[3]) < 2e-2, "dbias"
+    if res:
+        assert _rel(got[4], ref[4]) < 2e-2
+    assert _rel(got[5], ref[5]) < 1e-2 and _rel(got[6], ref[6]) < 1e-2
+
+
+def test_batchnorm_eval_and_frozen():
+    torch.manual_seed(3)
+    c = 64
+    x = _bf(torch.randn(2, c, 17, 17, device=DEV))
+    bn = ops.BatchNorm2d(c).to(DEV)
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2)
+    bn.eval()
+    y = bn(_nhwc(x), relu=True)
+    ref = F.relu(F.batch_norm(x.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, False))
+    assert _rel(y, ref) < 2e-2
+    bn.train()
+    bn.frozen = True
+    xh = _nhwc(x).requires_grad_(True)
+    bn(xh, relu=True).float().sum().backward()
+    xr = x.float().requires_grad_(True)
+    F.relu(F.batch_norm(xr, bn.running_mean, bn.running_var, bn.weight, bn.bias, False)).sum().backward()
+    assert _rel(xh.grad, xr.grad) < 2e-2
+
+
+# ----------------------------------------------------------------------------- loss / resize / pool
+@pytest.mark.parametrize("c,hw", [(21, 65), (21, 513), (7, 33)])
+def test_softmax_ce(c, hw):
+    torch.manual_seed(4)
+    n = 2
+    logits = _bf(torch.randn(n, c, hw, hw, device=DEV) * 3)
+    tgt = torch.randint(0, c, (n, hw, hw), device=DEV)
+    tgt[0, : hw // 4] = 255
+    lr = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(lr, tgt, ignore_index=255)
+    (ref * 0.5).backward()
+    lh = _nhwc(logits).requires_grad_(True)
+    got = ops.softmax_cross_entropy(lh, tgt.to(torch.uint8), 255)
+    (got * 0.5).backward()
+    assert abs(float(got) - float(ref)) < 2e-3 * max(1.0, abs(float(ref)))
+    assert _rel(lh.grad, lr.grad) < 2e-2
+    # all-ignored batch: loss 0, gradient 0, no NaN
+    tgt.fill_(255)
+    lh2 = _nhwc(logits).requires_grad_(True)
+    z = ops.softmax_cross_entropy(lh2, tgt, 255)
+    z.backward()
+    assert float(z) == 0.0 and float(lh2.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("c,hin,hout", [(256, 33, 129), (21, 129, 513), (48, 17, 65), (21, 33, 20), (64, 1, 9)])
+def test_bilinear(c, hin, hout):
+    torch.manual_seed(5)
+    x = _bf(torch.randn(2, c, hin, hin, device=DEV))
+    xr = x.float().requires_grad_(True)
+    yr = F.interpolate(xr, size=(hout, hout), mode="bilinear", align_corners=True)
+    gy = _bf(torch.randn_like(yr))
+    yr.backward(gy.float())
+    xh = _nhwc(x).requires_grad_(True)
+    yh = ops.bilinear_resize(xh, (hout, hout))
+    assert _rel(yh, yr) < 1e-2
+    yh.backward(_nhwc(gy))
+    assert _rel(xh.grad, xr.grad) < 1.5e-2
+
+
+def test_pools():
+    torch.manual_seed(6)
+    x = _bf(torch.randn(2, 64, 65, 67, device=DEV))
+    xr = x.float().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gy = _bf(torch.randn_like(yr))
+    yr.backward(gy.float())
+    xh = _nhwc(x).requires_grad_(True)
+    yh = ops.max_pool3x3s2(xh)
+    assert torch.equal(yh.float(), yr)
+    yh.backward(_nhwc(gy))
+    assert _rel(xh.grad, xr.grad) < 1e-2
+    x2 = _bf(torch.randn(3, 2048, 9, 9, device=DEV))
+    x2r = x2.float().requires_grad_(True)
+    pr = F.adaptive_avg_pool2d(x2r, 1)
+    g2 = _bf(torch.randn_like(pr))
+    pr.backward(g2.float())
+    x2h = _nhwc(x2).requires_grad_(True)
+    ph = ops.global_avg_pool(x2h)
+    assert _rel(ph, pr) < 1e-2
+    ph.backward(g2)
+    assert _rel(x2h.grad, x2r.grad) < 1e-2
+
+
+def test_sgd_flat_matches_torch():
+    torch.manual_seed(7)
+    nel = 100003
+    p0 = torch.randn(nel, device=DEV)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref_p], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    p, g, m = p0.clone(), torch.zeros(nel, device=DEV), torch.zeros(nel, device=DEV)
+    p16 = torch.zeros(nel, device=DEV, dtype=torch.bfloat16)
+    for step in range(3):
+        grad = torch.randn(nel, device=DEV)
+        ref_p.grad = grad.clone() * 0.5
+        opt.step()
+        g.copy_(grad)
+        ops.sgd_flat_step_(p, g, m, p16, 0.1, 0.9, 5e-4, grad_scale=0.5, zero_grad=True, first_step=(step == 0))
+        assert float(g.abs().max()) == 0.0
+    assert torch.allclose(p, ref_p.detach(), atol=1e-5, rtol=1e-5)
+    assert torch.equal(p16, p.to(torch.bfloat16))
+
+
+def test_affine_augment_matches_reference():
+    torch.manual_seed(8)
+    bsz, h, w = 3, 65, 77
+    img = torch.randint(0, 256, (bsz, h, w, 3), dtype=torch.uint8, device=DEV)
+    lab = torch.randint(0, 21, (bsz, h, w), dtype=torch.uint8, device=DEV)
+    mats = ops.make_affine_params(bsz, (h, w), (49, 49), scales=(0.5, 2.0), rots=(-10, 10),
+                                  rng=np.random.default_rng(0))
+    out, ol = ops.affine_augment(img, lab, mats, (49, 49))
+    with ops.backend("torch"):
+        ref, rl = ops.affine_augment(img, lab, mats, (49, 49), out_dtype=torch.float32)
+    assert out.shape == (bsz, 3, 49, 49) and out.is_contiguous(memory_format=torch.channels_last)
+    assert float((out.float() - ref).abs().max()) < 0.06
+    assert float((ol != rl).float().mean()) < 0.01   # nearest ties at .5 may differ
+
+
+def test_confusion_matrix():
+    torch.manual_seed(9)
+    k = 21
+    logits = _bf(torch.randn(2, k, 65, 65, device=DEV))
+    tgt = torch.randint(0, k, (2, 65, 65), device=DEV)
+    tgt[:, :3] = 255
+    cm = ops.confusion_matrix(_nhwc(logits), tgt, k)
+    with ops.backend("torch"):
+        ref = ops.confusion_matrix(logits.float(), tgt, k)
+    assert torch.equal(cm, ref)
+    pred = logits.float().argmax(1).to(torch.uint8)
+    cm2 = ops.confusion_matrix(pred, tgt.to(torch.uint8), k)
+    assert torch.equal(cm2, ref)
+
+
+# ----------------------------------------------------------------------------- end to end
+def test_model_step_matches_stock_path():
+    """One DeepLabv3+ (R18) training step through the HIP kernels vs the stock-op path."""
+    from distributedpytorch_amd.models import build_model
+    torch.manual_seed(10)
+    x = torch.randn(2, 3, 129, 129, device=DEV)
+    y = torch.randint(0, 21, (2, 129, 129), device=DEV)
+    y[:, :5] = 255
+    losses = {}
+    for backend in ("torch", "auto"):
+        torch.manual_seed(11)
+        m = build_model("deeplabv3plus_resnet18", 21).to(DEV).to(memory_format=torch.channels_last)
+        m.train()  # batch statistics keep activations O(1); same seed -> same dropout masks
+        torch.manual_seed(12)
+        with ops.backend(backend):
+            out = m(_nhwc(_bf(x)))
+            loss = ops.softmax_cross_entropy(out, y)
+        losses[backend] = float(loss)
+    assert abs(losses["auto"] - losses["torch"]) < 0.05 * abs(losses["torch"])
+
+
+def test_engine_trains():
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(12)
+    m = build_model("deeplabv3plus_resnet18", 21)
+    eng = TrainEngine(m, ops.SoftmaxCrossEntropy(255), lr=0.01, device=torch.device(DEV))
+    x = torch.randn(4, 3, 65, 65, device=DEV)
+    y = torch.randint(0, 21, (4, 65, 65), device=DEV)
+    first = float(eng.train_step(x, y))
+    for _ in range(15):
+        last = float(eng.train_step(x, y))
+    assert math.isfinite(last) and last < first
