@@ -21,6 +21,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxRowBlocks = 1024;
+constexpr int kReduceSlab = 8;
 
 struct Map {
     int cg;      // global channel-group index (8 channels)
@@ -30,10 +31,16 @@ struct Map {
     bool active;
 };
 
+// SLAB = channel groups per block.  Streaming kernels use 256 (a block spans up to 2048 channels,
+// rows fully contiguous).  Reduction kernels use 8 (a 64-channel = 128-byte slab per block, many
+// rows per thread): the number of blocks that end up adding into one channel's accumulator is
+// then the row-split count (tens), not the whole grid (a thousand) — contended fp32 atomics on
+// one line run an order of magnitude below the spread rate on MI355X.
+template <int SLAB>
 __device__ __forceinline__ Map make_map(int C8) {
     Map m;
-    const int base = blockIdx.y * kThreads;
-    m.cgs = min(kThreads, C8 - base);
+    const int base = blockIdx.y * SLAB;
+    m.cgs = min(SLAB, C8 - base);
     m.rpp = kThreads / m.cgs;
     const int cgl = threadIdx.x % m.cgs;
     m.rlane = threadIdx.x / m.cgs;
@@ -57,7 +64,7 @@ __device__ __forceinline__ void block_reduce_atomic(const Map& m, float (&acc)[N
 #pragma unroll
     for (int j = 0; j < NACC; ++j) smem[j * kThreads + threadIdx.x] = m.active ? acc[j] : 0.f;
     __syncthreads();
-    if (m.rlane == 0) {
+    if (m.rlane == 0 && threadIdx.x < m.cgs) {
         const int cgl = threadIdx.x;  // == cg - base because rlane == 0
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const bf16_raw* __re
                                                             float* __restrict__ sum, float* __restrict__ sq) {
     __shared__ float smem[16 * kThreads];
     const int C8 = C >> 3;
-    const Map m = make_map(C8);
+    const Map m = make_map<kReduceSlab>(C8);
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -122,7 +129,7 @@ struct ApplyArgs {
 template <bool FROM_STATS>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
     const int C8 = a.C >> 3;
-    const Map m = make_map(C8);
+    const Map m = make_map<kThreads>(C8);
     if (!m.active) return;
     float sc[8], sh[8];
     const int c0 = m.cg * 8;
@@ -202,7 +209,7 @@ __device__ __forceinline__ void masked_dy(const BwdArgs& a, int mode, const floa
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
     __shared__ float smem[16 * kThreads];
     const int C8 = a.C >> 3;
-    const Map m = make_map(C8);
+    const Map m = make_map<kReduceSlab>(C8);
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
 
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
     const int C8 = a.C >> 3;
-    const Map m = make_map(C8);
+    const Map m = make_map<kThreads>(C8);
     if (!m.active) return;
     const int c0 = m.cg * 8;
     float ka[8], kb[8], kc[8], sc[8], sh[8];
@@ -307,6 +314,18 @@ inline dim3 grid_for(long M, int C, int rows_per_thread) {
     return dim3((unsigned)nb, (unsigned)((C8 + kThreads - 1) / kThreads), 1);
 }
 
+// reduction kernels: grid = (row splits, 64-channel slabs); ~1024 blocks in total, ≥ 8 rows/thread
+inline dim3 grid_reduce(long M, int C) {
+    const int C8 = C / 8;
+    const int slabs = (C8 + kReduceSlab - 1) / kReduceSlab;
+    const int rpp = kThreads / kReduceSlab;
+    long splits = (1024 + slabs - 1) / slabs;
+    const long max_by_rows = (M + (long)rpp * 8 - 1) / ((long)rpp * 8);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    return dim3((unsigned)splits, (unsigned)slabs, 1);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -315,7 +334,7 @@ inline dim3 grid_for(long M, int C, int rows_per_thread) {
 // ---------------------------------------------------------------------------------------------
 DP_EXPORT int dp_bn_stats(const void* x, long M, int C, float* sum, float* sq, hipStream_t st) {
     if (C % 8 != 0 || M <= 0) return -1;
-    hipLaunchKernelGGL(bn_stats_kernel, grid_for(M, C, 8), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(bn_stats_kernel, grid_reduce(M, C), dim3(kThreads), 0, st,
                        (const bf16_raw*)x, M, C, sum, sq);
     return DP_LAUNCH_STATUS();
 }
@@ -354,7 +373,7 @@ DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, lon
     a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y; a.M = M; a.C = C;
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias;
     a.out_sdy = out_sdy; a.out_sdyx = out_sdyx; a.mask_mode = mask_mode;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid_for(M, C, 8), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid_reduce(M, C), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
 
