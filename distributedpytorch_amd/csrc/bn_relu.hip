@@ -124,6 +124,8 @@ struct ApplyArgs {
     float* mean_out; float* invstd_out; float* running_mean; float* running_var;
     float inv_count, eps, momentum, unbias;
     int relu;
+    int nrep;   // statistics replicas: sum/sq are [nrep][2][C] when produced by the conv epilogue
+    long rep_stride;
 };
 
 template <bool FROM_STATS>
@@ -136,8 +138,10 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (FROM_STATS) {
-            const float mean = a.sum[c0 + j] * a.inv_count;
-            const float var = fmaxf(fmaf(-mean, mean, a.sq[c0 + j] * a.inv_count), 0.f);
+            float s1 = a.sum[c0 + j], s2 = a.sq[c0 + j];
+            for (int r = 1; r < a.nrep; ++r) { s1 += a.sum[r * a.rep_stride + c0 + j]; s2 += a.sq[r * a.rep_stride + c0 + j]; }
+            const float mean = s1 * a.inv_count;
+            const float var = fmaxf(fmaf(-mean, mean, s2 * a.inv_count), 0.f);
             const float invstd = rsqrtf(var + a.eps);
             const float w = a.weight ? a.weight[c0 + j] : 1.f;
             const float b = a.bias ? a.bias[c0 + j] : 0.f;
@@ -190,6 +194,8 @@ struct BwdArgs {
     const float* sdy; const float* sdyx;   // bwd_apply inputs (null => frozen statistics)
     float* out_sdy; float* out_sdyx;       // bwd_reduce outputs
     float inv_count;
+    float* gw_sink; float* gb_sink;        // optional: += local Σdy'·x̂ / Σdy' (parameter-gradient arenas)
+    const float* lsdy; const float* lsdyx; // local (pre all-reduce) sums feeding the sinks
     int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0
 };
 
@@ -270,6 +276,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
         sc[j] = w * is;
         sh[j] = fmaf(-mu, sc[j], b);
         ka[j] = sc[j];
+        if (a.gw_sink && blockIdx.x == 0 && m.rlane == 0) {
+            a.gw_sink[c0 + j] += a.lsdyx[c0 + j];
+            a.gb_sink[c0 + j] += a.lsdy[c0 + j];
+        }
         if (a.sdy) {
             kb[j] = -sc[j] * is * a.sdyx[c0 + j] * a.inv_count;
             kc[j] = -sc[j] * a.sdy[c0 + j] * a.inv_count - kb[j] * mu;
@@ -342,7 +352,7 @@ DP_EXPORT int dp_bn_stats(const void* x, long M, int C, float* sum, float* sq, h
 DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M, int C, const float* sum,
                                 const float* sq, const float* weight, const float* bias, float* mean_out,
                                 float* invstd_out, float* running_mean, float* running_var, float count,
-                                float eps, float momentum, int relu, hipStream_t st) {
+                                float eps, float momentum, int relu, int nrep, long rep_stride, hipStream_t st) {
     if (C % 8 != 0 || M <= 0) return -1;
     ApplyArgs a{};
     a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
@@ -350,7 +360,7 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
     a.mean_out = mean_out; a.invstd_out = invstd_out; a.running_mean = running_mean; a.running_var = running_var;
     a.inv_count = 1.f / count; a.eps = eps; a.momentum = momentum;
     a.unbias = count > 1.f ? count / (count - 1.f) : 1.f;
-    a.relu = relu;
+    a.relu = relu; a.nrep = nrep < 1 ? 1 : nrep; a.rep_stride = rep_stride;
     hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
@@ -379,13 +389,15 @@ DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, lon
 
 DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, void* dres, long M, int C,
                               const float* mean, const float* invstd, const float* weight, const float* bias,
-                              const float* sdy, const float* sdyx, float count, int mask_mode, hipStream_t st) {
+                              const float* sdy, const float* sdyx, float count, int mask_mode, float* gw_sink,
+                              float* gb_sink, const float* lsdy, const float* lsdyx, hipStream_t st) {
     if (C % 8 != 0 || M <= 0) return -1;
     BwdArgs a{};
     a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y;
     a.dx = (bf16_raw*)dx; a.dres = (bf16_raw*)dres; a.M = M; a.C = C;
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias; a.sdy = sdy; a.sdyx = sdyx;
     a.inv_count = 1.f / count; a.mask_mode = mask_mode;
+    a.gw_sink = gw_sink; a.gb_sink = gb_sink; a.lsdy = lsdy; a.lsdyx = lsdyx;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }

@@ -43,7 +43,8 @@ struct ConvArgs {
     const bf16_raw* w;      // [Cout, R, S, Cin]
     bf16_raw* y;            // [M, ldy]
     const float* bias;      // [Cout] or null
-    float* stats;           // [2, Cout] (Σy, Σy²) or null
+    float* stats;           // [stat_reps, 2, Cout] (Σy, Σy²) or null
+    int stat_reps;
     long M;
     int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
     int smul, sdiv, pad_h, pad_w, dil_h, dil_w;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int AR = BM / 32, BR = BN / 32;            // load rounds (32 rows × 128 B per round)
     constexpr int C_LD = BN * 2 + 16;                    // epilogue LDS row stride (bytes)
-    static_assert(BM * C_LD <= 2 * STAGE, "epilogue tile must fit");
+    static_assert(BM * C_LD + WGM * BN * 8 <= 2 * STAGE, "epilogue tile + stats scratch must fit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -199,6 +200,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
     // accumulator element e of tile (mi, ni): row = wm*WTM + mi*32 + (e&3) + 8*(e>>2) + 4*fhalf,
     //                                         col = wn*WTN + ni*32 + frow
     const bool col_vec_ok = (p.Cout % 8 == 0) && (p.ldy % 8 == 0);
+    const bool do_stats = p.stats != nullptr;            // uniform
+    float* stat_scratch = reinterpret_cast<float*>(smem + BM * C_LD);   // [WGM][BN][2] floats
+    float st1[NI], st2[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int col = wn * WTN + ni * 32 + frow;
@@ -211,20 +215,46 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
                 const float v = acc[mi][ni][e] + bv;
-                if (p.stats && m0 + row < p.M) { s1 += v; s2 = fmaf(v, v, s2); }
+                if (do_stats) {
+                    const float vm = (m0 + row < p.M) ? v : 0.f;
+                    s1 += vm; s2 = fmaf(vm, vm, s2);
+                }
                 *reinterpret_cast<bf16_raw*>(smem + row * C_LD + col * 2) = f2bf(v);
             }
         }
-        if (p.stats) {
+        if (do_stats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (fhalf == 0 && gcol < p.Cout) {
-                atomicAdd(p.stats + gcol, s1);
-                atomicAdd(p.stats + p.Cout + gcol, s2);
+            // combine the WGM waves that share this column through LDS: one atomic pair per
+            // (block, channel), not per wave
+            if (fhalf == 0 && wm > 0) {
+                stat_scratch[((wm - 1) * BN + col) * 2 + 0] = s1;
+                stat_scratch[((wm - 1) * BN + col) * 2 + 1] = s2;
+            }
+        }
+        st1[ni] = s1; st2[ni] = s2;
+    }
+    __syncthreads();
+    if (do_stats && wm == 0 && fhalf == 0) {
+        // replica = tile_m mod R: spreads the per-channel atomics of the thousands of M-tiles of a
+        // large feature map over R lines (contended single-line fp32 atomics are ~14× slower)
+        float* dst = p.stats + (long)(tile_m % p.stat_reps) * 2 * p.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = wn * WTN + ni * 32 + frow;
+            const int gcol = n0 + col;
+            float s1 = st1[ni], s2 = st2[ni];
+#pragma unroll
+            for (int w2 = 1; w2 < WGM; ++w2) {
+                s1 += stat_scratch[((w2 - 1) * BN + col) * 2 + 0];
+                s2 += stat_scratch[((w2 - 1) * BN + col) * 2 + 1];
+            }
+            if (gcol < p.Cout) {
+                atomicAdd(dst + gcol, s1);
+                atomicAdd(dst + p.Cout + gcol, s2);
             }
         }
     }
-    __syncthreads();
     if (col_vec_ok) {
         constexpr int TPR = BN / 8;               // threads per row (16-B pieces)
         constexpr int RPP = kThreads / TPR;       // rows per pass
@@ -280,7 +310,8 @@ int launch(ConvArgs& p, hipStream_t st) {
 }  // namespace
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64
-DP_EXPORT int dp_conv_igemm(const void* x, const void* w, void* y, const float* bias, float* stats, int N, int Hi,
+DP_EXPORT int dp_conv_igemm(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
+                            int N, int Hi,
                             int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul, int sdiv, int pad_h,
                             int pad_w, int dil_h, int dil_w, int ldy, int tile, hipStream_t st) {
     if (Cin % 8 != 0 || Cin <= 0 || Cout <= 0 || N <= 0 || Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return -1;
@@ -290,6 +321,7 @@ DP_EXPORT int dp_conv_igemm(const void* x, const void* w, void* y, const float* 
         (long)Cout * R * S * Cin >= (1L << 31)) return -4;   // 32-bit element offsets in the kernel
     ConvArgs p{};
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.y = (bf16_raw*)y; p.bias = bias; p.stats = stats;
+    p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
     p.M = (long)N * Ho * Wo;
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
     p.smul = smul; p.sdiv = sdiv; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;

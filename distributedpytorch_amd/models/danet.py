@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import BatchNorm2d, Conv2d, bilinear_resize
+from ..ops import conv_bn_act, BatchNorm2d, Conv2d, bilinear_resize
 from .resnet import ResNet
 
 
@@ -62,7 +62,7 @@ class _ConvBNReLU(nn.Module):
         self.add_module("1", BatchNorm2d(cout))
 
     def forward(self, x):
-        return getattr(self, "1")(getattr(self, "0")(x), relu=True)
+        return conv_bn_act(getattr(self, "0"), getattr(self, "1"), x, relu=True)
 
 
 class _DropCls(nn.Module):

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import BatchNorm2d, Conv2d, GlobalAvgPool, bilinear_resize
+from ..ops import conv_bn_act, BatchNorm2d, Conv2d, GlobalAvgPool, bilinear_resize
 from .resnet import ResNet
 from .xception import AlignedXception
 
@@ -29,7 +29,7 @@ class _ASPPBranch(nn.Module):
         self.bn = BatchNorm2d(cout)
 
     def forward(self, x):
-        return self.bn(self.atrous_conv(x), relu=True)
+        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True)
 
 
 class _ImagePool(nn.Module):
@@ -42,8 +42,8 @@ class _ImagePool(nn.Module):
         self.add_module("2", BatchNorm2d(cout))
 
     def forward(self, x):
-        y = getattr(self, "1")(getattr(self, "0")(x))
-        return getattr(self, "2")(y, relu=True)
+        pooled = getattr(self, "0")(x)
+        return conv_bn_act(getattr(self, "1"), getattr(self, "2"), pooled, relu=True)
 
 
 class ASPP(nn.Module):
@@ -64,7 +64,7 @@ class ASPP(nn.Module):
         pooled = self.global_avg_pool(x)
         pooled = pooled.expand(-1, -1, h, w)  # align_corners bilinear of a 1×1 map = broadcast
         y = torch.cat([self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), pooled], dim=1)
-        y = self.bn1(self.conv1(y), relu=True)
+        y = conv_bn_act(self.conv1, self.bn1, y, relu=True)
         return F.dropout(y, self.p_drop, self.training)
 
 
@@ -80,9 +80,9 @@ class _LastConv(nn.Module):
         self.add_module("8", Conv2d(mid, num_classes, 1))
 
     def forward(self, x, training: bool):
-        x = getattr(self, "1")(getattr(self, "0")(x), relu=True)
+        x = conv_bn_act(getattr(self, "0"), getattr(self, "1"), x, relu=True)
         x = F.dropout(x, 0.5, training)
-        x = getattr(self, "5")(getattr(self, "4")(x), relu=True)
+        x = conv_bn_act(getattr(self, "4"), getattr(self, "5"), x, relu=True)
         x = F.dropout(x, 0.1, training)
         return getattr(self, "8")(x)
 
@@ -95,7 +95,7 @@ class Decoder(nn.Module):
         self.last_conv = _LastConv(256 + 48, num_classes)
 
     def forward(self, x, low):
-        low = self.bn1(self.conv1(low), relu=True)
+        low = conv_bn_act(self.conv1, self.bn1, low, relu=True)
         x = bilinear_resize(x, low.shape[2:])
         return self.last_conv(torch.cat([x, low], dim=1), self.training)
 

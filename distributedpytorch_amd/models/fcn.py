@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import BatchNorm2d, Conv2d, bilinear_resize
+from ..ops import conv_bn_act, BatchNorm2d, Conv2d, bilinear_resize
 from .resnet import ResNet
 
 
@@ -18,7 +18,7 @@ class FCNHead(nn.Module):
         self.cls = Conv2d(mid, num_classes, 1)
 
     def forward(self, x, training: bool):
-        x = self.bn(self.conv(x), relu=True)
+        x = conv_bn_act(self.conv, self.bn, x, relu=True)
         return self.cls(F.dropout(x, 0.1, training))
 
 

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
-from ..ops import BatchNorm2d, Conv2d, MaxPool3x3s2
+from ..ops import conv_bn_act, BatchNorm2d, Conv2d, MaxPool3x3s2
 
 
 class _Projection(nn.Module):
@@ -29,7 +29,7 @@ class _Projection(nn.Module):
         self.add_module("1", BatchNorm2d(cout))
 
     def forward(self, x):
-        return getattr(self, "1")(getattr(self, "0")(x))
+        return conv_bn_act(getattr(self, "0"), getattr(self, "1"), x)
 
 
 class BasicBlock(nn.Module):
@@ -46,8 +46,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), relu=True, residual=identity)
+        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity)
 
 
 class Bottleneck(nn.Module):
@@ -66,9 +66,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), relu=True, residual=identity)
+        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn_act(self.conv2, self.bn2, out, relu=True)
+        return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 
 _CFG = {
@@ -131,7 +131,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
+        x = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         x = self.maxpool(x)
         c2 = self.layer1(x)
         x = self.layer2(c2)

@@ -13,7 +13,7 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 
-from ..ops import BatchNorm2d, Conv2d
+from ..ops import conv_bn_act, BatchNorm2d, Conv2d
 
 
 class SeparableConv2d(nn.Module):
@@ -27,8 +27,11 @@ class SeparableConv2d(nn.Module):
         self.bn = BatchNorm2d(cin)
         self.pointwise = Conv2d(cin, cout, 1, bias=False)
 
+    def depthwise_bn(self, x):
+        return conv_bn_act(self.conv1, self.bn, x)
+
     def forward(self, x):
-        return self.pointwise(self.bn(self.conv1(x)))
+        return self.pointwise(self.depthwise_bn(x))
 
 
 class _Unit(nn.Module):
@@ -41,7 +44,7 @@ class _Unit(nn.Module):
         self.relu_after = relu_after
 
     def forward(self, x):
-        return self.bn(self.sep(x), relu=self.relu_after)
+        return conv_bn_act(self.sep.pointwise, self.bn, self.sep.depthwise_bn(x), relu=self.relu_after)
 
 
 class XceptionBlock(nn.Module):
@@ -78,7 +81,7 @@ class XceptionBlock(nn.Module):
         short = x
         x = self.rep(x)
         if self.skip is not None:
-            return self.skipbn(self.skip(short), residual=x)
+            return conv_bn_act(self.skip, self.skipbn, short, residual=x)
         return x + short
 
 
@@ -112,8 +115,8 @@ class AlignedXception(nn.Module):
         self.output_stride = output_stride
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
+        x = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        x = conv_bn_act(self.conv2, self.bn2, x, relu=True)
         x = self.block1(x)
         low = torch.relu(x)
         x = self.block2(low)
@@ -121,7 +124,7 @@ class AlignedXception(nn.Module):
         x = self.middle(x)
         x = self.block20(x)
         x = torch.relu(x)
-        x = self.bn3(self.conv3(x), relu=True)
-        x = self.bn4(self.conv4(x), relu=True)
-        x = self.bn5(self.conv5(x), relu=True)
+        x = conv_bn_act(self.conv3.pointwise, self.bn3, self.conv3.depthwise_bn(x), relu=True)
+        x = conv_bn_act(self.conv4.pointwise, self.bn4, self.conv4.depthwise_bn(x), relu=True)
+        x = conv_bn_act(self.conv5.pointwise, self.bn5, self.conv5.depthwise_bn(x), relu=True)
         return x, low

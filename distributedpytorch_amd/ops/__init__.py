@@ -1,10 +1,11 @@
 """Operator layer: hand-written gfx950 kernels behind autograd wrappers."""
+from . import workspace  # noqa: F401
 from ._backend import (NativeLibraryMissing, backend, get_backend, lib_built, set_backend,  # noqa: F401
                        use_hip)
 from .augment import IMAGENET_MEAN, IMAGENET_STD, affine_augment, make_affine_params  # noqa: F401
 from .batchnorm import (BatchNorm2d, batch_norm_act, convert_sync_batchnorm,  # noqa: F401
                         freeze_batchnorm)
-from .conv import Conv2d, conv2d, conv_out_size  # noqa: F401
+from .conv import Conv2d, conv2d, conv_bn_act, conv_out_size  # noqa: F401
 from .loss import SoftmaxCrossEntropy, softmax_cross_entropy  # noqa: F401
 from .metrics import confusion_matrix, miou_from_confusion  # noqa: F401
 from .pool import GlobalAvgPool, MaxPool3x3s2, global_avg_pool, max_pool3x3s2  # noqa: F401

@@ -8,6 +8,7 @@ from ctypes import c_float, c_int, c_long, c_void_p
 import torch
 
 from . import _backend as B
+from . import workspace
 
 _sigs_done = False
 
@@ -18,12 +19,13 @@ def _lib():
     if not _sigs_done:
         lib.dp_bn_stats.argtypes = [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]
         lib.dp_bn_apply_stats.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int] + [c_void_p] * 8 + \
-            [c_float, c_float, c_float, c_int, c_void_p]
+            [c_float, c_float, c_float, c_int, c_int, c_long, c_void_p]
         lib.dp_bn_apply_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p,
                                            c_int, c_void_p]
         lib.dp_bn_bwd_reduce.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int] + [c_void_p] * 6 + \
             [c_int, c_void_p]
-        lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int, c_void_p]
+        lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int] + \
+            [c_void_p] * 5
         _sigs_done = True
     return lib
 
@@ -59,7 +61,7 @@ def stats(x: torch.Tensor):
     x = as_nhwc(x)
     _check_act(x, "x")
     M, C = _mc(x)
-    buf = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    buf = workspace.zeros(2 * C, x.device).view(2, C)
     B.check(_lib().dp_bn_stats(B.ptr(x), M, C, B.ptr(buf[0]), B.ptr(buf[1]), B.stream_ptr()), "bn_stats")
     return buf[0], buf[1]
 
@@ -80,12 +82,21 @@ def apply(x, scale, shift, residual, relu):
     return y
 
 
-def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var, count, eps, momentum, relu):
+def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var, count, eps, momentum, relu,
+                     replicas=None):
     """Training form: finalises mean/invstd/running stats inside the apply kernel.
-    Returns (y, mean, invstd)."""
+    ``replicas``: optional fp32 [R, 2, C] partial statistics from the conv epilogue (then ``s``/``ss``
+    are ignored and the kernel sums the R replicas itself).  Returns (y, mean, invstd)."""
     x = as_nhwc(x)
     _check_act(x, "x")
     M, C = _mc(x)
+    nrep, rep_stride = 1, 0
+    if replicas is not None:
+        if replicas.dtype != torch.float32 or replicas.dim() != 3 or replicas.shape[1:] != (2, C) \
+                or not replicas.is_contiguous():
+            raise ValueError("replicas must be contiguous fp32 [R, 2, C]")
+        nrep, rep_stride = replicas.shape[0], 2 * C
+        s, ss = replicas[0, 0], replicas[0, 1]
     for t, nm in ((s, "sum"), (ss, "sqsum"), (weight, "weight"), (bias, "bias"),
                   (running_mean, "running_mean"), (running_var, "running_var")):
         _check_vec(t, C, nm)
@@ -97,7 +108,8 @@ def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var
     B.check(_lib().dp_bn_apply_stats(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(s), B.ptr(ss),
                                      B.ptr(weight), B.ptr(bias), B.ptr(mi[0]), B.ptr(mi[1]),
                                      B.ptr(running_mean), B.ptr(running_var), float(count), float(eps),
-                                     float(momentum), int(relu), B.stream_ptr()), "bn_apply_stats")
+                                     float(momentum), int(relu), int(nrep), int(rep_stride), B.stream_ptr()),
+            "bn_apply_stats")
     return y, mi[0], mi[1]
 
 
@@ -109,14 +121,15 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode):
         _check_act(y, "y", x)
     for t, nm in ((mean, "mean"), (invstd, "invstd"), (weight, "weight"), (bias, "bias")):
         _check_vec(t, C, nm)
-    buf = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    buf = workspace.zeros(2 * C, x.device).view(2, C)
     B.check(_lib().dp_bn_bwd_reduce(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), M, C,
                                     B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                     B.ptr(buf[0]), B.ptr(buf[1]), int(mask_mode), B.stream_ptr()), "bn_bwd_reduce")
     return buf[0], buf[1]
 
 
-def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres):
+def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres,
+              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None):
     dy = as_nhwc(dy)
     _check_act(x, "x"); _check_act(dy, "dy", x)
     M, C = _mc(x)
@@ -125,10 +138,14 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
     for t, nm in ((mean, "mean"), (invstd, "invstd"), (weight, "weight"), (bias, "bias"),
                   (sdy, "sdy"), (sdyx, "sdyx")):
         _check_vec(t, C, nm)
+    if gw_sink is not None:
+        for t, nm in ((gw_sink, "gw_sink"), (gb_sink, "gb_sink"), (lsdy, "lsdy"), (lsdyx, "lsdyx")):
+            _check_vec(t, C, nm)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if need_dres else None
     B.check(_lib().dp_bn_bwd_apply(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), B.ptr(dx),
                                    B.ptr(dres), M, C, B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
-                                   B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.stream_ptr()),
+                                   B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.ptr(gw_sink),
+                                   B.ptr(gb_sink), B.ptr(lsdy), B.ptr(lsdyx), B.stream_ptr()),
             "bn_bwd_apply")
     return dx, dres

@@ -16,6 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _backend as B
+from . import workspace
 from ._hip_bn import as_nhwc
 
 _sigs_done = False
@@ -26,7 +27,7 @@ def _lib():
     lib = B.lib()
     if not _sigs_done:
         V, I = c_void_p, c_int
-        lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 17 + [V]
+        lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
@@ -63,9 +64,13 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != cout):
         raise ValueError("igemm: bias must be fp32[Cout]")
-    if stats is not None and (stats.dtype != torch.float32 or stats.numel() != 2 * cout):
-        raise ValueError("igemm: stats must be fp32[2,Cout]")
-    B.check(_lib().dp_conv_igemm(B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(bias), B.ptr(stats), n, hi, wi, cin,
+    reps = 1
+    if stats is not None:
+        if stats.dtype != torch.float32 or stats.dim() != 3 or tuple(stats.shape[1:]) != (2, cout) \
+                or not stats.is_contiguous():
+            raise ValueError("igemm: stats must be contiguous fp32 [R, 2, Cout]")
+        reps = stats.shape[0]
+    B.check(_lib().dp_conv_igemm(B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(bias), B.ptr(stats), reps, n, hi, wi, cin,
                                  ho, wo, cout, r, s, smul, sdiv, pad[0], pad[1], dil[0], dil[1], cout, tile,
                                  B.stream_ptr()), "conv_igemm")
     return y
@@ -85,13 +90,26 @@ def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
     return wt
 
 
-def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil) -> torch.Tensor:
-    """dw fp32, logical [Cout,Cin,R,S] stored channels-last (KRSC)."""
+def stat_replicas(m_rows: int) -> int:
+    """Replica count for the fused-statistics accumulators: ~one replica per 64 M-tiles, ≤ 8."""
+    tiles = (m_rows + 127) // 128
+    return max(1, min(8, tiles // 64))
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None) -> torch.Tensor:
+    """dw fp32, logical [Cout,Cin,R,S] stored channels-last (KRSC).  ``out``: accumulate into this
+    tensor (the parameter-gradient arena view) instead of a fresh zeroed one."""
     cout, cin, r, s = wshape
     n, _, hi, wi = x.shape
     _, _, ho, wo = dy.shape
-    dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
-                     memory_format=torch.channels_last).zero_()
+    if out is not None:
+        if out.dtype != torch.float32 or tuple(out.shape) != (cout, cin, r, s) or \
+                not out.permute(0, 2, 3, 1).is_contiguous():
+            raise ValueError("wgrad: out must be fp32 [Cout,Cin,R,S] stored KRSC")
+        dw = out
+    else:
+        dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
+                         memory_format=torch.channels_last).zero_()
     B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
                                  stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 0, 0, B.stream_ptr()),
             "conv_wgrad")
@@ -100,7 +118,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil) -> torch.
 
 class _ConvIGemm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation):
+    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation, with_stats=False):
         cout, cin, r, s = weight.shape
         n, _, hi, wi = x.shape
         ho = _out_size(hi, r, stride[0], padding[0], dilation[0])
@@ -122,16 +140,26 @@ class _ConvIGemm(torch.autograd.Function):
         if bias is not None:
             b32 = torch.zeros(cout_p, dtype=torch.float32, device=x.device)
             b32[:cout] = bias.detach().float()
-        y = igemm(x, w_used, (ho, wo), stride[0], 1, padding, dilation, b32)
+        stats = None
+        if with_stats:
+            if cout_p != cout:
+                raise ValueError("fused statistics need Cout % 8 == 0")
+            reps = stat_replicas(n * ho * wo)
+            stats = workspace.zeros(reps * 2 * cout, x.device).view(reps, 2, cout)
+        y = igemm(x, w_used, (ho, wo), stride[0], 1, padding, dilation, b32, stats)
         ctx.save_for_backward(x, w_used)
         ctx.geom = (stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p)
         ctx.has_bias = bias is not None
+        ctx.weight_param = weight
         if cout_p != cout:
             y = y[:, :cout]
+        if with_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, w_used = ctx.saved_tensors
         stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p = ctx.geom
         if cout_p != cout:
@@ -148,12 +176,23 @@ class _ConvIGemm(torch.autograd.Function):
             if cin_p != cin:
                 dx = dx[:, :cin]
         if ctx.needs_input_grad[1]:
-            dw = wgrad(dy, x, (cout_p, cin_p, r, s), stride, padding, dilation)
-            if cout_p != cout or cin_p != cin:
-                dw = dw[:cout, :cin]
+            wp = ctx.weight_param
+            sink = getattr(wp, "_dpamd_grad_sink", None)
+            if (sink is not None and cout_p == cout and cin_p == cin and wp.grad is not None
+                    and wp.grad.data_ptr() == sink.data_ptr()):
+                # accumulate straight into the gradient arena (the kernel adds with fp32 atomics):
+                # no temporary, no zero-fill, no AccumulateGrad add; then tell the DDP bucketer
+                wgrad(dy, x, (cout, cin, r, s), stride, padding, dilation, out=sink)
+                notify = getattr(wp, "_dpamd_on_grad", None)
+                if notify is not None:
+                    notify(wp)
+            else:
+                dw = wgrad(dy, x, (cout_p, cin_p, r, s), stride, padding, dilation)
+                if cout_p != cout or cin_p != cin:
+                    dw = dw[:cout, :cin]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(dim=(0, 2, 3))[:cout]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _DepthwiseConv(torch.autograd.Function):
@@ -186,21 +225,23 @@ class _DepthwiseConv(torch.autograd.Function):
             B.check(_lib().dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), n, c, hi, wi, ho, wo, stride[0],
                                               padding[0], padding[1], dilation[0], B.stream_ptr()), "dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
-            dw9 = torch.zeros((9, c), dtype=torch.float32, device=x.device)
+            dw9 = workspace.zeros(9 * c, x.device).view(9, c)
             B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo, stride[0],
                                                 padding[0], padding[1], dilation[0], B.stream_ptr()),
                     "dwconv_bwd_weight")
-            dw = dw9.t().reshape(c, 1, 3, 3)
+            dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
         return dx, dw, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp):
+def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False):
     if x.dtype != torch.bfloat16:
         raise TypeError(f"HIP conv path needs bf16 activations, got {x.dtype}")
     if w_lowp is None:
         w_lowp = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if groups == 1:
-        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation)
+        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats)
+    if with_stats:
+        raise NotImplementedError("fused statistics are only produced by the dense implicit-GEMM kernel")
     if groups == x.shape[1] == weight.shape[0] and weight.shape[1] == 1:
         if bias is not None:
             raise NotImplementedError("depthwise bias")

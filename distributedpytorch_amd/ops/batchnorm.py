@@ -79,18 +79,26 @@ def _group_active(group) -> bool:
 # --------------------------------------------------------------------------------------
 class _BatchNormActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group,
+                conv_stats=None):
         C = x.shape[1]
         local_count = x.numel() // C
         hip = B.use_hip(x)
+        sync = _group_active(group)
+        replicas = None
         if hip:
             from . import _hip_bn
             x = _hip_bn.as_nhwc(x)
-            s, ss = _hip_bn.stats(x)
+            if conv_stats is not None and not sync:
+                replicas, s, ss = conv_stats, None, None      # summed inside the apply kernel
+            elif conv_stats is not None:
+                red = conv_stats.sum(0)
+                s, ss = red[0], red[1]
+            else:
+                s, ss = _hip_bn.stats(x)
         else:
             s, ss = _t_stats(x)
         count = float(local_count)
-        sync = _group_active(group)
         pg = None if group is True else group
         if sync:
             # C4: one fused message [Σx | Σx² | count] per layer (2C+1 floats).
@@ -108,7 +116,7 @@ class _BatchNormActTrain(torch.autograd.Function):
             w = weight.detach().float().contiguous() if weight is not None else None
             b = bias.detach().float().contiguous() if bias is not None else None
             y, mean, invstd = _hip_bn.apply_from_stats(x, s, ss, w, b, residual, running_mean, running_var,
-                                                       count, eps, momentum, relu)
+                                                       count, eps, momentum, relu, replicas)
             mask_mode = 0 if not relu else (1 if residual is not None else 2)
             ctx.save_for_backward(x, y if mask_mode == 1 else None, w, b, mean, invstd)
             ctx.mask_mode = mask_mode
@@ -131,6 +139,7 @@ class _BatchNormActTrain(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.has_affine = weight is not None
         ctx.wdtype = weight.dtype if weight is not None else None
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -149,14 +158,30 @@ class _BatchNormActTrain(torch.autograd.Function):
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.pg)
             g_sdy, g_sdyx = packed[:C].contiguous(), packed[C:].contiguous()
         if ctx.hip:
+            wp, bp = ctx.params
+            gw = getattr(wp, "_dpamd_grad_sink", None) if ctx.has_affine else None
+            gb = getattr(bp, "_dpamd_grad_sink", None) if ctx.has_affine else None
+            use_sink = (gw is not None and gb is not None and wp.grad is not None and bp.grad is not None
+                        and wp.grad.data_ptr() == gw.data_ptr() and bp.grad.data_ptr() == gb.data_ptr()
+                        and ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
+            if use_sink:
+                # affine gradients are added into the gradient arena by the same kernel
+                dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
+                                             ctx.mask_mode, need_dres, gw, gb, sdy, sdyx)
+                for prm in (wp, bp):
+                    notify = getattr(prm, "_dpamd_on_grad", None)
+                    if notify is not None:
+                        notify(prm)
+                return dx, None, None, dres, None, None, None, None, None, None, None
             dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
                                          ctx.mask_mode, need_dres)
         else:
             dx, dres = _t_bwd_apply(dy, x, y, mean, invstd, w, g_sdy, g_sdyx, ctx.count, ctx.relu, need_dres)
         # affine grads are *local* sums: DDP's gradient all-reduce averages them like any other param
-        dweight = sdyx.to(ctx.wdtype) if ctx.has_affine else None
-        dbias = sdy.to(ctx.wdtype) if ctx.has_affine else None
-        return dx, dweight, dbias, dres, None, None, None, None, None, None
+        # clone: the sums may live in the per-step scratch pool, autograd may keep the tensor as .grad
+        dweight = sdyx.to(ctx.wdtype, copy=True) if ctx.has_affine else None
+        dbias = sdy.to(ctx.wdtype, copy=True) if ctx.has_affine else None
+        return dx, dweight, dbias, dres, None, None, None, None, None, None, None
 
 
 class _BatchNormActFrozen(torch.autograd.Function):
@@ -192,7 +217,8 @@ class _BatchNormActFrozen(torch.autograd.Function):
 
 def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, training: bool,
                    momentum: float = 0.1, eps: float = 1e-5, relu: bool = False,
-                   residual: Optional[torch.Tensor] = None, group=False) -> torch.Tensor:
+                   residual: Optional[torch.Tensor] = None, group=False,
+                   conv_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``act(BN(x) + residual)``.  ``group``: ``False`` = local statistics, ``True`` = default
     process group, or a ``ProcessGroup`` = statistics all-reduced over that group."""
     if B.get_backend() == "torch" and not _group_active(group):
@@ -203,7 +229,7 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
         return F.relu(y) if relu else y
     if training:
         return _BatchNormActTrain.apply(x, weight, bias, residual, running_mean, running_var,
-                                        momentum, eps, relu, group)
+                                        momentum, eps, relu, group, conv_stats)
     invstd = torch.rsqrt(running_var.float() + eps)
     scale = invstd * (weight.float() if weight is not None else 1.0)
     shift = (bias.float() if bias is not None else 0.0) - running_mean.float() * scale
@@ -230,13 +256,14 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
+                stats: Optional[torch.Tensor] = None):
         training = self.training and not self.frozen
         group = False
         if self.sync and training:
             group = self.process_group if self.process_group is not None else True
         return batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                              training, self.momentum, self.eps, relu, residual, group)
+                              training, self.momentum, self.eps, relu, residual, group, stats)
 
     def extra_repr(self) -> str:
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "

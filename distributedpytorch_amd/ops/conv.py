@@ -37,12 +37,17 @@ def conv_out_size(n: int, k: int, s: int, p: int, d: int) -> int:
 # --------------------------------------------------------------------------------------
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            stride: _IntOr2 = 1, padding: _IntOr2 = 0, dilation: _IntOr2 = 1, groups: int = 1,
-           w_lowp: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """2-D convolution.  ``w_lowp`` is an optional up-to-date bf16 KRSC copy of ``weight``."""
+           w_lowp: Optional[torch.Tensor] = None, with_stats: bool = False):
+    """2-D convolution.  ``w_lowp`` is an optional up-to-date bf16 KRSC copy of ``weight``.
+
+    ``with_stats`` (GPU, dense conv only) additionally returns the per-channel ``[R, 2, Cout]``
+    partial sums Σy, Σy² accumulated in the kernel epilogue — the BatchNorm statistics for free."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     if B.use_hip(x):
         from . import _hip_conv
-        return _hip_conv.conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp)
+        return _hip_conv.conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats)
+    if with_stats:
+        raise ValueError("with_stats is a GPU-kernel feature")
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = None if bias is None else bias.to(x.dtype)
     return F.conv2d(x, w, b, stride, padding, dilation, groups)
@@ -94,10 +99,14 @@ class Conv2d(nn.Module):
             self._lowp_version = w._version
         return self._lowp
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, with_stats: bool = False):
         w_lowp = self.lowp_weight(x.dtype) if (B.use_hip(x) and x.dtype != self.weight.dtype) else None
         return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                      self.groups, w_lowp)
+                      self.groups, w_lowp, with_stats)
+
+    def can_fuse_stats(self, x: torch.Tensor) -> bool:
+        return (B.use_hip(x) and self.groups == 1 and self.out_channels % 8 == 0
+                and x.dtype == torch.bfloat16)
 
     def extra_repr(self) -> str:
         s = f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}"
@@ -110,3 +119,13 @@ class Conv2d(nn.Module):
         if self.bias is None:
             s += ", bias=False"
         return s
+
+
+def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(BN(conv(x)) + residual)``.  On the GPU path the batch statistics come out of the conv
+    kernel's epilogue (no separate statistics pass over the activation)."""
+    if bn.training and not bn.frozen and conv.can_fuse_stats(x):
+        y, stats = conv(x, with_stats=True)
+        return bn(y, relu=relu, residual=residual, stats=stats)
+    return bn(conv(x), relu=relu, residual=residual)

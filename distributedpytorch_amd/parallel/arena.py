@@ -86,6 +86,8 @@ class ParamArena:
                 view.copy_(s.param.data)
                 s.param.data = view
                 s.param.grad = _view_like(self.flat_g, s.offset, s.param)
+                # kernels that produce this parameter's gradient add straight into the arena
+                s.param._dpamd_grad_sink = s.param.grad
                 if self.flat_lowp is not None:
                     lv = _view_like(self.flat_lowp, s.offset, s.param)
                     self.lowp_views[id(s.param)] = lv
@@ -141,6 +143,7 @@ class ParamArena:
                     view.copy_(s.param.data)
                     s.param.data = view
                 s.param.grad = _view_like(self.flat_g, s.offset, s.param)
+                s.param._dpamd_grad_sink = s.param.grad
         self.refresh_lowp()
 
     def zero_grad(self) -> None:

@@ -70,7 +70,11 @@ class DistributedDataParallel(nn.Module):
 
     def _install_hooks(self) -> None:
         for si, slot in enumerate(self.arena.slots):
-            slot.param.register_post_accumulate_grad_hook(self._make_hook(si))
+            hook = self._make_hook(si)
+            slot.param.register_post_accumulate_grad_hook(hook)
+            # kernels that add into the arena directly (conv wgrad, BN affine grads) return no
+            # gradient to autograd, so they report readiness through this attribute instead
+            slot.param._dpamd_on_grad = hook
 
     def _make_hook(self, si: int):
         bucket = self.arena.slots[si].bucket

@@ -19,7 +19,7 @@ from typing import Callable, Dict, Iterable, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from ..ops import confusion_matrix, miou_from_confusion
+from ..ops import confusion_matrix, miou_from_confusion, workspace
 from ..utils.timers import PhaseTimer
 from . import dist_env
 from .ddp import DistributedDataParallel
@@ -74,6 +74,7 @@ class TrainEngine:
         # TODO `train_pascal.py:5`: "label non_blocking = True"
         y = target.to(self.device, non_blocking=True)
         last_micro = (self._micro + 1) % self.accum_steps == 0
+        workspace.begin_step(self.device)   # one memset re-arms every reduction accumulator of the step
         with self.timer.phase("fwd"):
             out = self.ddp(x)
             loss = self.criterion(out, y)

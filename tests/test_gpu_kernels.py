@@ -109,6 +109,40 @@ def test_depthwise(stride, dil):
     assert _rel(wh.grad, wr.grad) < 1.5e-2
 
 
+def test_conv_fused_statistics():
+    """Σy, Σy² from the conv epilogue (replicated accumulators) == statistics of the output."""
+    torch.manual_seed(20)
+    for (n, cin, cout, hw, k) in [(4, 64, 128, 65, 3), (2, 256, 64, 33, 1), (16, 64, 256, 65, 1)]:
+        x = _nhwc(_bf(torch.randn(n, cin, hw, hw, device=DEV)))
+        w = _bf(torch.randn(cout, cin, k, k, device=DEV) / math.sqrt(cin * k * k)).float()
+        y, stats = ops.conv2d(x, w, None, 1, k // 2, 1, with_stats=True)
+        s = stats.sum(0)
+        yf = F.conv2d(x.float().cpu(), w.cpu(), None, 1, k // 2, 1)
+        assert _rel(s[0], yf.sum(dim=(0, 2, 3))) < 2e-3
+        assert _rel(s[1], (yf * yf).sum(dim=(0, 2, 3))) < 2e-3
+
+
+def test_conv_bn_act_fused_matches_unfused():
+    torch.manual_seed(21)
+    conv = ops.Conv2d(64, 128, 3, padding=1, bias=False).to(DEV)
+    bn = ops.BatchNorm2d(128).to(DEV)
+    x = _nhwc(_bf(torch.randn(4, 64, 33, 33, device=DEV)))
+    res = _nhwc(_bf(torch.randn(4, 128, 33, 33, device=DEV)))
+    outs = []
+    for fused in (True, False):
+        conv.zero_grad(); bn.zero_grad()
+        bn.running_mean.zero_(); bn.running_var.fill_(1)
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            y = ops.conv_bn_act(conv, bn, xi, relu=True, residual=res)
+        else:
+            y = bn(conv(xi), relu=True, residual=res)
+        y.float().square().mean().backward()
+        outs.append((y.detach(), xi.grad, conv.weight.grad.clone(), bn.weight.grad.clone(), bn.running_var.clone()))
+    for a, b in zip(*outs):
+        assert _rel(a, b) < 2e-2
+
+
 # ----------------------------------------------------------------------------- batch norm
 @pytest.mark.parametrize("shape", [(2, 64, 33, 33), (3, 48, 17, 9), (2, 2048, 9, 9), (2, 728, 17, 17),
                                    (1, 4096, 5, 5)])
