@@ -57,10 +57,39 @@ __device__ __forceinline__ void stg16(bf16_raw* p, long chunk, const uint4& v) {
 }
 
 // Block-level combine of NACC per-thread accumulators over row lanes, then atomics.
+// Fast path (full 8-group slab): lanes of a wave are [8 row lanes][8 channel groups], so three
+// xor-shuffles (8, 16, 32) fold the row lanes in registers; the four waves then meet in 2 KB of LDS
+// and 128 threads issue the atomics (one per channel and statistic).
 template <int NACC>
 __device__ __forceinline__ void block_reduce_atomic(const Map& m, float (&acc)[NACC], float* smem,
                                                     float* out0, float* out1, int C) {
-    // smem layout [NACC][kThreads]
+    static_assert(NACC == 16, "two statistics x 8 channels");
+    if (m.cgs == 8) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            float v = acc[j];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[j] = v;
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane < 8) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) smem[(wave * 8 + lane) * NACC + j] = acc[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 * NACC) {
+            const int cgl = threadIdx.x / NACC, j = threadIdx.x % NACC;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) s += smem[(w * 8 + cgl) * NACC + j];
+            const int c = (blockIdx.y * kReduceSlab + cgl) * 8 + (j & 7);
+            atomicAdd((j < 8 ? out0 : out1) + c, s);
+        }
+        return;
+    }
+    // generic path (ragged last slab): smem layout [NACC][kThreads]
 #pragma unroll
     for (int j = 0; j < NACC; ++j) smem[j * kThreads + threadIdx.x] = m.active ? acc[j] : 0.f;
     __syncthreads();
@@ -79,6 +108,11 @@ __device__ __forceinline__ void block_reduce_atomic(const Map& m, float (&acc)[N
             atomicAdd(out1 + c0 + j, acc[8 + j]);
         }
     }
+}
+
+__device__ __forceinline__ void load8f(const float* p, float* f) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const bf16_raw* __restrict__ x, long M, int C,
@@ -135,19 +169,28 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
     if (!m.active) return;
     float sc[8], sh[8];
     const int c0 = m.cg * 8;
+    if (FROM_STATS) {
+        float s1[8], s2[8], wv[8], bv[8];
+        load8f(a.sum + c0, s1);
+        load8f(a.sq + c0, s2);
+        for (int r = 1; r < a.nrep; ++r) {
+            float t1[8], t2[8];
+            load8f(a.sum + r * a.rep_stride + c0, t1);
+            load8f(a.sq + r * a.rep_stride + c0, t2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (FROM_STATS) {
-            float s1 = a.sum[c0 + j], s2 = a.sq[c0 + j];
-            for (int r = 1; r < a.nrep; ++r) { s1 += a.sum[r * a.rep_stride + c0 + j]; s2 += a.sq[r * a.rep_stride + c0 + j]; }
-            const float mean = s1 * a.inv_count;
-            const float var = fmaxf(fmaf(-mean, mean, s2 * a.inv_count), 0.f);
+            for (int j = 0; j < 8; ++j) { s1[j] += t1[j]; s2[j] += t2[j]; }
+        }
+        if (a.weight) load8f(a.weight + c0, wv);
+        if (a.bias) load8f(a.bias + c0, bv);
+        const bool finalise = blockIdx.x == 0 && m.rlane == 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float mean = s1[j] * a.inv_count;
+            const float var = fmaxf(fmaf(-mean, mean, s2[j] * a.inv_count), 0.f);
             const float invstd = rsqrtf(var + a.eps);
-            const float w = a.weight ? a.weight[c0 + j] : 1.f;
-            const float b = a.bias ? a.bias[c0 + j] : 0.f;
-            sc[j] = w * invstd;
-            sh[j] = fmaf(-mean, sc[j], b);
-            if (blockIdx.x == 0 && m.rlane == 0) {
+            sc[j] = (a.weight ? wv[j] : 1.f) * invstd;
+            sh[j] = fmaf(-mean, sc[j], a.bias ? bv[j] : 0.f);
+            if (finalise) {
                 a.mean_out[c0 + j] = mean;
                 a.invstd_out[c0 + j] = invstd;
                 if (a.running_mean) {
@@ -156,10 +199,10 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
                     a.running_var[c0 + j] = fmaf(a.momentum, uv - a.running_var[c0 + j], a.running_var[c0 + j]);
                 }
             }
-        } else {
-            sc[j] = a.scale[c0 + j];
-            sh[j] = a.shift[c0 + j];
         }
+    } else {
+        load8f(a.scale + c0, sc);
+        load8f(a.shift + c0, sh);
     }
     const long stride = (long)gridDim.x * m.rpp;
     const bool has_res = a.res != nullptr;
@@ -221,15 +264,15 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     if (m.active) {
         const int c0 = m.cg * 8;
-        float mu[8], is[8], sc[8], sh[8];
+        float mu[8], is[8], sc[8], sh[8], wv[8], bv[8];
+        load8f(a.mean + c0, mu);
+        load8f(a.invstd + c0, is);
+        if (a.weight) load8f(a.weight + c0, wv);
+        if (a.bias) load8f(a.bias + c0, bv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            mu[j] = a.mean[c0 + j];
-            is[j] = a.invstd[c0 + j];
-            const float w = a.weight ? a.weight[c0 + j] : 1.f;
-            const float b = a.bias ? a.bias[c0 + j] : 0.f;
-            sc[j] = w * is[j];
-            sh[j] = fmaf(-mu[j], sc[j], b);
+            sc[j] = (a.weight ? wv[j] : 1.f) * is[j];
+            sh[j] = fmaf(-mu[j], sc[j], a.bias ? bv[j] : 0.f);
         }
         const long stride = (long)gridDim.x * m.rpp;
         for (long r = (long)blockIdx.x * m.rpp + m.rlane; r < a.M; r += 2 * stride) {
@@ -268,23 +311,31 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
     if (!m.active) return;
     const int c0 = m.cg * 8;
     float ka[8], kb[8], kc[8], sc[8], sh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float mu = a.mean[c0 + j], is = a.invstd[c0 + j];
-        const float w = a.weight ? a.weight[c0 + j] : 1.f;
-        const float b = a.bias ? a.bias[c0 + j] : 0.f;
-        sc[j] = w * is;
-        sh[j] = fmaf(-mu, sc[j], b);
-        ka[j] = sc[j];
+    {
+        float mu[8], is[8], wv[8], bv[8], gs[8], gx[8];
+        load8f(a.mean + c0, mu);
+        load8f(a.invstd + c0, is);
+        if (a.weight) load8f(a.weight + c0, wv);
+        if (a.bias) load8f(a.bias + c0, bv);
+        if (a.sdy) { load8f(a.sdy + c0, gs); load8f(a.sdyx + c0, gx); }
         if (a.gw_sink && blockIdx.x == 0 && m.rlane == 0) {
-            a.gw_sink[c0 + j] += a.lsdyx[c0 + j];
-            a.gb_sink[c0 + j] += a.lsdy[c0 + j];
+            float lw[8], lb[8];
+            load8f(a.lsdyx + c0, lw);
+            load8f(a.lsdy + c0, lb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a.gw_sink[c0 + j] += lw[j]; a.gb_sink[c0 + j] += lb[j]; }
         }
-        if (a.sdy) {
-            kb[j] = -sc[j] * is * a.sdyx[c0 + j] * a.inv_count;
-            kc[j] = -sc[j] * a.sdy[c0 + j] * a.inv_count - kb[j] * mu;
-        } else {
-            kb[j] = 0.f; kc[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = (a.weight ? wv[j] : 1.f) * is[j];
+            sh[j] = fmaf(-mu[j], sc[j], a.bias ? bv[j] : 0.f);
+            ka[j] = sc[j];
+            if (a.sdy) {
+                kb[j] = -sc[j] * is[j] * gx[j] * a.inv_count;
+                kc[j] = -sc[j] * gs[j] * a.inv_count - kb[j] * mu[j];
+            } else {
+                kb[j] = 0.f; kc[j] = 0.f;
+            }
         }
     }
     const long stride = (long)gridDim.x * m.rpp;
