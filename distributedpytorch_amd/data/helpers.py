@@ -113,7 +113,12 @@ def fixed_resize(sample: np.ndarray, resolution, flagval=None) -> np.ndarray:
         h, w = arr.shape[:2]
         s = float(resolution) / min(h, w)
         resolution = (int(round(h * s)), int(round(w * s)))
-    return imgproc.resize(arr, tuple(int(v) for v in resolution), flagval)
+    out = imgproc.resize(arr, tuple(int(v) for v in resolution), flagval)
+    if flagval == imgproc.INTER_CUBIC and arr.size:
+        # bicubic overshoots; keep the value range of the input so the 0..255 data contract the
+        # reference asserts on every batch (train_pascal.py:188-189) holds for float images too
+        np.clip(out, arr.min(), arr.max(), out=out)
+    return out
 
 
 def crop2fullmask(crop_mask: np.ndarray, bbox, im=None, im_size=None, zero_pad: bool = False, relax: int = 0,
