@@ -366,7 +366,9 @@ class NEllipseWithGaussians:
             pts = _points(target, 0, self.is_val is True)
             z1, z2 = compute_nellipse_gaussianHM_fast(np.arange(target.shape[0]), np.arange(target.shape[1]), pts)
             z = 255.0 * z1 + self.alpha * 255.0 * z2
-            sample["nellipseWithGaussians"] = (z * (255.0 / max(float(z.max()), 1e-10))).astype(np.float32)
+            # min(): z·(255/max) can land one float32 ulp above 255 and trip the 0..255 batch assert (train_pascal.py:189)
+            z = (z * (255.0 / max(float(z.max()), 1e-10))).astype(np.float32)
+            sample["nellipseWithGaussians"] = np.minimum(z, np.float32(255.0), out=z)
         return sample
 
     def __str__(self):

@@ -36,7 +36,10 @@ def softmax_cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_ind
     """Mean CE over non-ignored pixels.  ``logits`` [N,C,H,W], ``target`` [N,H,W] integer."""
     if B.use_hip(logits):
         return _SoftmaxCEHip.apply(logits, target, ignore_index)
-    return F.cross_entropy(logits.float(), target.long(), ignore_index=ignore_index)
+    # same convention as the kernel: Σ loss / max(valid pixels, 1) — an all-ignored batch gives 0, not NaN
+    t = target.long()
+    total = F.cross_entropy(logits.float(), t, ignore_index=ignore_index, reduction="sum")
+    return total / (t != ignore_index).sum().clamp_min(1).to(total.dtype)
 
 
 class SoftmaxCrossEntropy(nn.Module):

@@ -100,9 +100,9 @@ def main():
         t_w = timeit(lambda: _hip_conv.wgrad(dy, x, (cout_p, cin_p, k, k), (stride, stride), (pad, pad), (dil, dil)))
         line = (f"{name:16s} {cnt:3d} {gf:7.1f} | {t_f:8.1f} {gf / t_f * 1e3:6.1f} | {t_d:8.1f} {gf / t_d * 1e3:6.1f} | "
                 f"{t_w:8.1f} {gf / t_w * 1e3:6.1f}")
-        tot["fwd"] += cnt * t_f
-        tot["dgrad"] += cnt * t_d
-        tot["wgrad"] += cnt * t_w
+        tot['fwd'] += cnt * t_f
+        tot['dgrad'] += cnt * t_d
+        tot['wgrad'] += cnt * t_w
         tot_fl += cnt * gf
         if args.stock:
             xs = x.detach().clone().requires_grad_(True)
@@ -117,9 +117,9 @@ def main():
             tot["sbwd"] += cnt * t_sb
             line += f" | {t_sf:8.1f} {t_sb:8.1f}"
         print(line, flush=True)
-    print(f"TOTAL weighted: fwd {tot['fwd'] / 1e3:.2f} ms ({tot_fl / tot["fwd"] * 1e3:.0f} TF)  "
-          f"dgrad {tot['dgrad'] / 1e3:.2f} ms ({tot_fl / tot["dgrad"] * 1e3:.0f} TF)  "
-          f"wgrad {tot['wgrad'] / 1e3:.2f} ms ({tot_fl / tot["wgrad"] * 1e3:.0f} TF)  [{tot_fl / 1e3:.2f} TFLOP per pass]")
+    print(f"TOTAL weighted: fwd {tot['fwd'] / 1e3:.2f} ms ({tot_fl / tot['fwd'] * 1e3:.0f} TF)  "
+          f"dgrad {tot['dgrad'] / 1e3:.2f} ms ({tot_fl / tot['dgrad'] * 1e3:.0f} TF)  "
+          f"wgrad {tot['wgrad'] / 1e3:.2f} ms ({tot_fl / tot['wgrad'] * 1e3:.0f} TF)  [{tot_fl / 1e3:.2f} TFLOP per pass]")
     if args.stock:
         print(f"STOCK (MIOpen): fwd {tot['sfwd'] / 1e3:.2f} ms  bwd(dgrad+wgrad) {tot['sbwd'] / 1e3:.2f} ms")
 
