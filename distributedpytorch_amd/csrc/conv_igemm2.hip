@@ -1,0 +1,394 @@
+// Implicit-GEMM (dilated) convolution, second-generation kernel for gfx950 — forward (K1) and
+// data-gradient (K2).  Same math and layouts as conv_igemm.hip (activations NHWC bf16, weights
+// KRSC bf16, output NHWC bf16 with row stride ldy), restructured around what the rocprofv3 counters
+// of the first kernel showed on the ResNet-101 layer-3 shapes (profiles/r1_pmc_l3_convs_v4_b32.txt):
+// 7.4 VALU instructions per MFMA (address generation), 18 % MFMA utilisation, each K-step exposed to
+// a full memory round trip because only ONE stage was ever in flight.
+//
+//   * operand tiles are fetched with `buffer_load_dwordx4 … lds` through buffer descriptors: the
+//     per-lane byte offset is computed ONCE, every K-step only adds a wave-uniform (SGPR) tap/channel
+//     offset, and padding / tails are a per-lane "offset := out-of-range" select — the hardware range
+//     check writes the zeros.  Padding validity of the R·S taps is a per-row bit mask built in the
+//     prologue, so a K-step costs 4 VALU per activation load and 0 per weight load (1×1, pad 0: 0).
+//   * NST-deep LDS ring (2–4 stages) with counted `s_waitcnt vmcnt(N)` and raw `s_barrier`: NST-1
+//     stages stay in flight across the barrier instead of draining every step.
+//   * 8-wave (512-thread) block tiles up to 256×256 for the wide layers (31 B/clk/CU of operand
+//     traffic at MFMA peak instead of 64 for 128²), 4-wave 128×128/128×64 for the small ones.
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the A operand: a lane's 4 accumulator
+//     registers are then 4 consecutive output channels of one pixel, so the epilogue packs them to
+//     one 8-byte LDS store (4× fewer LDS stores than column-per-lane), and the tile leaves LDS as
+//     coalesced 16-byte row stores.
+//   * fused BatchNorm statistics: per-lane Σ / Σ² over the pixel tiles in registers, 16-lane DPP
+//     row reduction, cross-wave combine in LDS, one coalesced fp32 atomic pair per (block, channel).
+//   * strided data-gradient needs no special loop: with sdiv = forward stride, a tap is valid only
+//     where (out − pad + r·dil) is a multiple of sdiv, and there floor(base/sdiv) + ceil(tap/sdiv)
+//     is exact, so the per-lane base and the uniform tap offset stay separable.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;                       // K elements per step (128 B per operand row)
+constexpr unsigned kOOB = 0x80000000u;       // byte offset beyond any descriptor (tensors < 2 GiB)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+struct Conv2Args {
+    const bf16_raw* x;      // [N, Hi, Wi, Cin]
+    const bf16_raw* w;      // [Cout, R, S, Cin]
+    bf16_raw* y;            // [M, ldy]
+    const float* bias;      // [Cout] or null
+    float* stats;           // [stat_reps, 2, Cout] or null (never together with bias)
+    int stat_reps;
+    int M;
+    int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
+    int smul, sdl, pad_h, pad_w, dil_h, dil_w;   // sdl = log2(sdiv)
+    int ldy;
+    int csteps, ksteps, ctail;
+    int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff,
+                                          unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
+                                             soff, 0, 0);
+}
+
+// sum over the 16 lanes of a DPP row (all lanes of the row end up with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2Args p) {
+    constexpr int T = 64 * WGM * WGN;
+    constexpr int RPR = T / 8;                           // tile rows filled per load round
+    constexpr int AR = BM / RPR, BR = BN / RPR;          // load rounds per stage
+    constexpr int L = AR + BR;                           // LDS-DMA instructions per thread per stage
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile: pixels × channels
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int C_LD = BN * 2 + 8;                     // epilogue row stride: 16 rows -> 32 distinct banks
+    static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must be whole load rounds");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be whole 16x16 MFMA tiles");
+    static_assert((NST - 1) * L <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile mapping (bijective for any grid size) ----
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n;
+    const int tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- per-thread load geometry: lane -> (row rr of the round, physical 16-B chunk pc) ----
+    const int pc = tid & 7;
+    const int rr = tid >> 3;
+    const int lc = pc ^ ((rr >> 1) & 7);     // logical chunk fetched (source-side swizzle)
+    unsigned a_voff[AR], a_mask[AR];
+    {
+        const int sdm = (1 << p.sdl) - 1;
+        int m = m0 + rr;
+        int ox = m % p.Wo;
+        int t = m / p.Wo;
+        int oy = t % p.Ho;
+        int n = t / p.Ho;
+        const int adv_x = RPR % p.Wo, adv_y = RPR / p.Wo;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int by = oy * p.smul - p.pad_h, bx = ox * p.smul - p.pad_w;
+            const int fby = by >> p.sdl, fbx = bx >> p.sdl;          // floor division (arithmetic shift)
+            const unsigned base = (unsigned)((((n * p.Hi + fby) * p.Wi + fbx) * p.Cin + lc * 8) * 2);
+            const bool row_ok = m < p.M;
+            if (UNIT) {
+                a_voff[i] = row_ok ? base : kOOB;
+                a_mask[i] = 0;
+            } else {
+                unsigned vx = 0, mk = 0;
+                for (int s = 0; s < p.S; ++s) {
+                    const int ix = bx + s * p.dil_w;
+                    const unsigned ok = (unsigned)((ix & sdm) == 0) & (unsigned)((unsigned)(ix >> p.sdl) < (unsigned)p.Wi);
+                    vx |= ok << s;
+                }
+                for (int r = 0; r < p.R; ++r) {
+                    const int iy = by + r * p.dil_h;
+                    const bool ok = ((iy & sdm) == 0) & ((unsigned)(iy >> p.sdl) < (unsigned)p.Hi);
+                    mk |= ok ? (vx << (r * p.S)) : 0u;
+                }
+                a_voff[i] = base;
+                a_mask[i] = row_ok ? mk : 0u;
+            }
+            // next round: RPR pixels further
+            m += RPR;
+            ox += adv_x; oy += adv_y;
+            if (ox >= p.Wo) { ox -= p.Wo; oy += 1; }
+            while (oy >= p.Ho) { oy -= p.Ho; n += 1; }
+        }
+    }
+    unsigned b_voff[BR];
+    {
+        const int w_row_stride = p.R * p.S * p.Cin;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + i * RPR + rr;
+            b_voff[i] = n < p.Cout ? (unsigned)((n * w_row_stride + lc * 8) * 2) : kOOB;
+        }
+    }
+
+    // ---- K-step iterator of the ISSUE side (uniform): filter tap (kr, ks), 64-channel slice kc ----
+    int kr = 0, ks = 0, kc = 0;
+    const int sdr = (1 << p.sdl) - 1;
+    auto issue_stage = [&](int buf) {
+        unsigned char* abase = smem + buf * STAGE + wave * (8 * 128);
+        unsigned char* bbase = abase + A_BYTES;
+        const unsigned w_soff = (unsigned)(((kr * p.S + ks) * p.Cin + kc * BK) * 2);
+        if (UNIT) {
+            const unsigned a_soff = (unsigned)(kc * BK * 2);
+            if (p.ctail) {
+                const bool cv = lc * 8 < p.Cin - kc * BK;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * 128), cv ? a_voff[i] : kOOB, a_soff);
+            } else {
+#pragma unroll
+                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * 128), a_voff[i], a_soff);
+            }
+        } else {
+            const int cdy = (kr * p.dil_h + sdr) >> p.sdl, cdx = (ks * p.dil_w + sdr) >> p.sdl;   // ceil(tap / sdiv)
+            const unsigned a_soff = (unsigned)(((cdy * p.Wi + cdx) * p.Cin + kc * BK) * 2);
+            const unsigned tapbit = 1u << (kr * p.S + ks);
+            const bool cv = !p.ctail || (lc * 8 < p.Cin - kc * BK);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = ((a_mask[i] & tapbit) != 0) & cv;
+                // the sum is formed per lane: the base may be "negative" (padding) and only base+tap is in range
+                lds_dma16(rx, abase + i * (RPR * 128), ok ? a_voff[i] + a_soff : kOOB, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) lds_dma16(rw, bbase + i * (RPR * 128), b_voff[i], w_soff);
+        if (++kc == p.csteps) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+    };
+
+    // ---- accumulators: acc[mi][ni][j] = out(pixel tile mi, lane&15 ; channel tile ni, (lane>>4)*4 + j) ----
+    f32x4v acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int fsw = l15 >> 1;                                   // read-side swizzle (tile bases are multiples of 16)
+    const int x_row_off = (wm * WTM + l15) * 128;
+    const int w_row_off = A_BYTES + (wn * WTN + l15) * 128;
+    const int ch0 = ((q ^ fsw) << 4), ch1 = (((4 + q) ^ fsw) << 4);
+
+    // ---- prologue: NST-1 stages in flight ----
+    const int ksteps = p.ksteps;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < ksteps) issue_stage(s);
+
+    int buf = 0;
+    for (int t = 0; t < ksteps; ++t) {
+        // stage t must have landed; up to NST-2 younger stages may stay in flight
+        const int younger = min(NST - 2, ksteps - 1 - t);
+        if (NST >= 4 && younger >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * L>();
+        else if (NST >= 3 && younger >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * L>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of the buffer about to be refilled are done
+        __builtin_amdgcn_s_barrier();
+        if (t + NST - 1 < ksteps) {
+            int ib = buf + NST - 1;
+            if (ib >= NST) ib -= NST;
+            issue_stage(ib);
+        }
+        const unsigned char* St = smem + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk == 0 ? ch0 : ch1;
+            bf16x8 wf[NI], xf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                wf[ni] = *reinterpret_cast<const bf16x8*>(St + w_row_off + ni * (16 * 128) + chunk);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                xf[mi] = *reinterpret_cast<const bf16x8*>(St + x_row_off + mi * (16 * 128) + chunk);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+        }
+        if (++buf == NST) buf = 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // all waves done reading operand tiles; LDS is reused for the epilogue
+
+    // ---- epilogue ----
+    const bool do_stats = p.stats != nullptr;                                // uniform
+    float* stat_scratch = reinterpret_cast<float*>(smem + BM * C_LD);        // [WGM][2][BN]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = wn * WTN + ni * 16 + q * 4;          // first of this lane's 4 channels (tile-local)
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n0 + col + j < p.Cout) b4[j] = p.bias[n0 + col + j];
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * WTM + mi * 16 + l15;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + b4[j];
+            if (do_stats) {
+                // rows beyond M were fed zeros and there is no bias on this path: they add exactly 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+            }
+            uint2 pk;
+            pk.x = pack2(v[0], v[1]);
+            pk.y = pack2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(smem + row * C_LD + col * 2) = pk;
+        }
+        if (do_stats) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]); }
+            if (l15 == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    stat_scratch[(wm * 2 + 0) * BN + col + j] = s1[j];
+                    stat_scratch[(wm * 2 + 1) * BN + col + j] = s2[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (do_stats) {
+        // replica = tile_m mod R spreads the per-channel atomics of a large map over R cache lines
+        float* dst = p.stats + (long)(tile_m % p.stat_reps) * 2 * p.Cout;
+        for (int i = tid; i < 2 * BN; i += T) {
+            const int which = i / BN, c = i - which * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WGM; ++w2) v += stat_scratch[(w2 * 2 + which) * BN + c];
+            if (n0 + c < p.Cout) atomicAdd(dst + which * p.Cout + n0 + c, v);
+        }
+    }
+    {
+        constexpr int TPR = BN / 8;               // threads per row (16-B pieces)
+        constexpr int RPP = T / TPR;              // rows per pass
+        const int cpiece = tid % TPR, rsub = tid / TPR;
+        const int gcol = n0 + cpiece * 8;
+#pragma unroll 4
+        for (int r0 = 0; r0 < BM; r0 += RPP) {
+            const int row = r0 + rsub;
+            const int m = m0 + row;
+            if (m < p.M && gcol < p.Cout) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
+                const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
+                *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW>
+int launch2(Conv2Args& p, bool unit, hipStream_t st) {
+    constexpr int T = 64 * WGM * WGN;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const long nwg = (long)p.tiles_m * p.tiles_n;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return -4;
+    constexpr int stage_bytes = NST * (BM + BN) * 128;
+    constexpr int epi_bytes = BM * (BN * 2 + 8) + WGM * 2 * BN * 4;
+    constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (unit) {
+        auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true>;
+        if (lds > 64 * 1024) {
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
+    } else {
+        auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false>;
+        if (lds > 64 * 1024) {
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
+    }
+    return DP_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+// cfg: 1 = 128x128 4-wave 2-stage   2 = 128x128 4-wave 4-stage   3 = 256x128 8-wave 3-stage
+//      4 = 128x256 8-wave 3-stage   5 = 256x256 8-wave 2-stage   6 = 256x64 8-wave 3-stage
+//      7 = 128x64 4-wave 3-stage    8 = 160x128 / 9 = 192x128 4-wave 2-stage (tile-count quantisation)
+//      10 = 256x128 8-wave 2-stage
+// Returns -2 for shapes this kernel does not take (R*S > 32, bias together with stats, Cout % 8):
+// the caller then uses conv_igemm.hip.
+DP_EXPORT int dp_conv_igemm2(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
+                             int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
+                             int sdiv, int pad_h, int pad_w, int dil_h, int dil_w, int ldy, int cfg, hipStream_t st) {
+    if (Cin % 8 != 0 || Cin <= 0 || Cout <= 0 || N <= 0 || Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return -1;
+    if (ldy < Cout || R <= 0 || S <= 0 || smul < 1 || (sdiv != 1 && sdiv != 2 && sdiv != 4)) return -1;
+    if (R * S > 32 || (bias && stats) || Cout % 8 != 0 || ldy % 8 != 0) return -2;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return -3;
+    const long x_bytes = (long)N * Hi * Wi * Cin * 2, w_bytes = (long)Cout * R * S * Cin * 2;
+    // 32-bit byte offsets below the out-of-range marker, with room for the largest tap offset
+    if (x_bytes >= (1L << 31) - (1L << 24) || w_bytes >= (1L << 31) - (1L << 24) || (long)N * Ho * Wo >= (1L << 31) - 512)
+        return -4;
+    Conv2Args p{};
+    p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.y = (bf16_raw*)y; p.bias = bias; p.stats = stats;
+    p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
+    p.M = (int)((long)N * Ho * Wo);
+    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
+    p.smul = smul; p.sdl = sdiv == 1 ? 0 : (sdiv == 2 ? 1 : 2);
+    p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
+    p.ldy = ldy;
+    p.csteps = (Cin + BK - 1) / BK;
+    p.ksteps = R * S * p.csteps;
+    p.ctail = (Cin % BK) != 0;
+    p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
+    const bool unit = (R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && sdiv == 1);
+    switch (cfg) {
+        case 1: return launch2<128, 128, 2, 2, 2, 2>(p, unit, st);
+        case 2: return launch2<128, 128, 2, 2, 4, 1>(p, unit, st);
+        case 3: return launch2<256, 128, 4, 2, 3, 2>(p, unit, st);
+        case 4: return launch2<128, 256, 2, 4, 3, 2>(p, unit, st);
+        case 5: return launch2<256, 256, 2, 4, 2, 2>(p, unit, st);
+        case 6: return launch2<256, 64, 4, 2, 3, 2>(p, unit, st);
+        case 7: return launch2<128, 64, 2, 2, 3, 1>(p, unit, st);
+        case 8: return launch2<160, 128, 2, 2, 2, 2>(p, unit, st);
+        case 9: return launch2<192, 128, 2, 2, 2, 2>(p, unit, st);
+        case 10: return launch2<256, 128, 4, 2, 2, 2>(p, unit, st);
+        default: return -2;
+    }
+}

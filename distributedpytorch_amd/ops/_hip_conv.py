@@ -10,6 +10,7 @@ a kernel.
 """
 from __future__ import annotations
 
+import os
 from ctypes import c_int, c_void_p
 from typing import Optional, Tuple
 
@@ -28,6 +29,7 @@ def _lib():
     if not _sigs_done:
         V, I = c_void_p, c_int
         lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
+        lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
@@ -47,7 +49,7 @@ def _round8(c: int) -> int:
 
 def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
           pad: Tuple[int, int], dil: Tuple[int, int], bias: Optional[torch.Tensor] = None,
-          stats: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+          stats: Optional[torch.Tensor] = None, tile: int = 0, cfg: Optional[int] = None) -> torch.Tensor:
     """Raw kernel call.  ``x`` [N,Cin,Hi,Wi] channels-last bf16; ``w_krsc`` logical [Cout,Cin,R,S]
     stored channels-last (memory [Cout][R][S][Cin]).  Returns [N,Cout,Ho,Wo] channels-last bf16."""
     n, cin, hi, wi = x.shape
@@ -70,10 +72,68 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
                 or not stats.is_contiguous():
             raise ValueError("igemm: stats must be contiguous fp32 [R, 2, Cout]")
         reps = stats.shape[0]
-    B.check(_lib().dp_conv_igemm(B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(bias), B.ptr(stats), reps, n, hi, wi, cin,
-                                 ho, wo, cout, r, s, smul, sdiv, pad[0], pad[1], dil[0], dil[1], cout, tile,
-                                 B.stream_ptr()), "conv_igemm")
+    args = (B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(bias), B.ptr(stats), reps, n, hi, wi, cin,
+            ho, wo, cout, r, s, smul, sdiv, pad[0], pad[1], dil[0], dil[1], cout)
+    if cfg is None:
+        cfg = _FORCED_CFG
+    if cfg is None:
+        key = (n, hi, wi, cin, ho, wo, cout, r, s, smul, sdiv, pad, dil, bias is not None, stats is not None)
+        cfg = _TUNED.get(key)
+        if cfg is None:
+            cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device) if _AUTOTUNE else 1
+    if cfg > 0:
+        st = _lib().dp_conv_igemm2(*args, cfg, B.stream_ptr())
+        if st != -2:       # -2: shape not taken by the second-generation kernel (7x7 stem, bias+stats)
+            B.check(st, "conv_igemm2")
+            return y
+    B.check(_lib().dp_conv_igemm(*args, tile, B.stream_ptr()), "conv_igemm")
     return y
+
+
+# ---- tile-configuration choice -------------------------------------------------------------------
+# Which tile wins depends on how the tile COUNT quantises against 256 CUs x blocks/CU for the actual
+# batch (measured: the same layer-3 conv takes 35 us at 546 tiles and 22 us at 512), so the choice is
+# measured once per distinct problem: every candidate runs a few times on the real operands (the
+# statistics go to a scratch buffer meanwhile), the fastest is cached for the life of the process.
+_FORCED_CFG = int(os.environ["DPAMD_CONV_CFG"]) if "DPAMD_CONV_CFG" in os.environ else None
+_AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
+_CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 0)
+_TUNED: dict = {}
+
+
+def _autotune(args, stats, reps, cout, device) -> int:
+    lib = _lib()
+    stream = B.stream_ptr()
+    a = list(args)
+    if stats is not None:
+        scratch = torch.zeros(reps * 2 * cout, dtype=torch.float32, device=device)
+        a[4] = B.ptr(scratch)
+
+    def run(c):
+        if c == 0:
+            return lib.dp_conv_igemm(*a, 0, stream)
+        return lib.dp_conv_igemm2(*a, c, stream)
+
+    timed = []
+    for c in _CANDIDATES:
+        st = run(c)                      # warm-up (also tells whether the kernel takes this shape)
+        if st == -2:
+            continue
+        B.check(st, "conv autotune")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            run(c)
+        e1.record()
+        timed.append((c, e0, e1))
+    torch.cuda.synchronize()
+    best = min(timed, key=lambda t: t[1].elapsed_time(t[2]))
+    return best[0]
+
+
+def tuned_table() -> dict:
+    """The configurations picked so far (for logs / bench reports)."""
+    return dict(_TUNED)
 
 
 def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:

@@ -91,6 +91,54 @@ def test_conv_identity_asymmetric():
     assert torch.allclose(y.float().cpu(), ref, atol=2e-2, rtol=1e-2)
 
 
+IGEMM2_CASES = [
+    # n, cin, cout, h, w, k, stride, pad, dil
+    (2, 64, 128, 33, 33, 1, 1, 0, 1),
+    (3, 128, 320, 33, 31, 3, 1, 1, 1),      # Cout tail for every tile width
+    (1, 256, 256, 33, 33, 3, 1, 6, 6),
+    (3, 512, 64, 9, 9, 3, 1, 18, 18),       # halo larger than the map
+    (2, 64, 128, 65, 65, 3, 2, 1, 1),       # strided: dgrad runs the sdiv=2 tap-parity path
+    (2, 128, 256, 33, 35, 1, 2, 0, 1),      # 1x1 stride 2 (projection shortcut)
+    (2, 304, 256, 17, 17, 3, 1, 1, 1),      # Cin tail (not a multiple of 64)
+    (2, 72, 48, 19, 19, 1, 1, 0, 1),        # Cin tail on the 1x1 fast path, Cout = 48
+    (5, 64, 64, 129, 129, 3, 1, 1, 1),      # many M tiles, M tail
+]
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("case", IGEMM2_CASES)
+def test_igemm2_all_tile_configs(case, cfg):
+    """csrc/conv_igemm2.hip: every tile configuration, forward + data-gradient + fused statistics,
+    against an fp32 CPU convolution."""
+    from distributedpytorch_amd.ops import _hip_conv
+    n, cin, cout, h, w, k, stride, pad, dil = case
+    torch.manual_seed(3)
+    x = _bf(torch.randn(n, cin, h, w, device=DEV))
+    wt = _bf(torch.randn(cout, cin, k, k, device=DEV) / math.sqrt(cin * k * k))
+    xr = x.float().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wt.float().cpu(), None, stride, pad, dil)
+    ho, wo = yr.shape[2:]
+    gy = _bf(torch.randn_like(yr)).to(DEV)
+    yr.backward(gy.float().cpu())
+    xh, wh = _nhwc(x), _nhwc(wt)
+    reps = 3
+    stats = torch.zeros(reps, 2, cout, device=DEV)
+    y = _hip_conv.igemm(xh, wh, (ho, wo), stride, 1, (pad, pad), (dil, dil), None, stats, cfg=cfg)
+    assert _rel(y, yr) < 1.5e-2
+    s = stats.sum(0).cpu()
+    yd = yr.detach()
+    # Σy cancels heavily: bound the error by the mass it was summed from
+    assert float((s[0] - yd.sum(dim=(0, 2, 3))).abs().max()) < 5e-3 * float(yd.abs().sum(dim=(0, 2, 3)).max())
+    assert _rel(s[1], (yd * yd).sum(dim=(0, 2, 3))) < 5e-3
+    bias = torch.randn(cout, device=DEV)
+    yb = _hip_conv.igemm(xh, wh, (ho, wo), stride, 1, (pad, pad), (dil, dil), bias, None, cfg=cfg)
+    assert _rel(yb, yr.detach() + bias.cpu().view(1, -1, 1, 1)) < 1.5e-2
+    wT = _hip_conv.weight_transpose(wh)
+    pad_t = dil * (k - 1) - pad
+    dx = _hip_conv.igemm(_nhwc(gy), wT, (h, w), 1, stride, (pad_t, pad_t), (dil, dil), cfg=cfg)
+    assert _rel(dx, xr.grad) < 1.5e-2
+
+
 @pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
 def test_depthwise(stride, dil):
     torch.manual_seed(1)

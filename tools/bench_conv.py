@@ -56,19 +56,62 @@ R101_DEEPLAB = [
 ]
 
 
-def timeit(fn, iters=5, warm=2):
+def timeit(fn, iters=5, warm=2, inner=10):
+    """Median µs per call; ``inner`` calls are queued back to back between the two events so the
+    host-side launch cost of one call hides behind the previous kernel."""
     for _ in range(warm):
         fn()
     ts = []
     for _ in range(iters):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
         a.record()
-        fn()
+        for _ in range(inner):
+            fn()
         b.record()
         b.synchronize()
-        ts.append(a.elapsed_time(b) * 1e3)
+        ts.append(a.elapsed_time(b) * 1e3 / inner)
     ts.sort()
     return ts[len(ts) // 2]
+
+
+def sweep(args):
+    """fwd (with fused statistics) and dgrad time of every requested tile config, per layer."""
+    cfgs = [int(c) for c in args.cfgs.split(",")]
+    dev = "cuda"
+    print(f"{'layer':16s} {'cnt':>3s} {'M':>7s} {'N':>5s} {'K':>6s} | " + " ".join(f"f{c:<6d}" for c in cfgs) + " | "
+          + " ".join(f"d{c:<6d}" for c in cfgs) + " | best fwd/dgrad")
+    tot_f = {c: 0.0 for c in cfgs}
+    tot_d = {c: 0.0 for c in cfgs}
+    best_f = best_d = 0.0
+    for name, cnt, cin, cout, hw, k, stride, pad, dil in R101_DEEPLAB:
+        if (args.filter and args.filter not in name) or k == 7:
+            continue
+        n = args.batch
+        ho = (hw + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        cin_p, cout_p = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+        x = torch.randn(n, cin_p, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout_p, cin_p, k, k, device=dev) / (cin * k * k) ** 0.5).to(torch.bfloat16) \
+            .contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(n, cout_p, ho, ho, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wt = _hip_conv.weight_transpose(w)
+        pad_t = dil * (k - 1) - pad
+        reps = _hip_conv.stat_replicas(n * ho * ho)
+        stats = torch.zeros(reps, 2, cout_p, device=dev)
+        tf, td = {}, {}
+        for c in cfgs:
+            tf[c] = timeit(lambda: _hip_conv.igemm(x, w, (ho, ho), stride, 1, (pad, pad), (dil, dil), None, stats, cfg=c))
+            td[c] = timeit(lambda: _hip_conv.igemm(dy, wt, (hw, hw), 1, stride, (pad_t, pad_t), (dil, dil), cfg=c))
+            tot_f[c] += cnt * tf[c]
+            tot_d[c] += cnt * td[c]
+        bf, bd = min(tf, key=tf.get), min(td, key=td.get)
+        best_f += cnt * tf[bf]
+        best_d += cnt * td[bd]
+        print(f"{name:16s} {cnt:3d} {n * ho * ho:7d} {cout_p:5d} {cin_p * k * k:6d} | "
+              + " ".join(f"{tf[c]:7.1f}" for c in cfgs) + " | " + " ".join(f"{td[c]:7.1f}" for c in cfgs)
+              + f" | {bf} {bd}", flush=True)
+    print("TOTAL ms       " + " " * 27 + " ".join(f"{tot_f[c] / 1e3:7.2f}" for c in cfgs) + " | "
+          + " ".join(f"{tot_d[c] / 1e3:7.2f}" for c in cfgs) + f" | best-per-layer fwd {best_f / 1e3:.2f} dgrad {best_d / 1e3:.2f}")
 
 
 def main():
@@ -76,6 +119,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--stock", action="store_true", help="also time MIOpen through F.conv2d")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--cfgs", default="", help="comma list of conv_igemm2 tile configs to sweep (0 = gen-1 kernel)")
     args = ap.parse_args()
     dev = "cuda"
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "sfwd": 0.0, "sbwd": 0.0}
@@ -117,6 +161,9 @@ def main():
             tot["sbwd"] += cnt * t_sb
             line += f" | {t_sf:8.1f} {t_sb:8.1f}"
         print(line, flush=True)
+    if args.cfgs:
+        sweep(args)
+        return
     print(f"TOTAL weighted: fwd {tot['fwd'] / 1e3:.2f} ms ({tot_fl / tot['fwd'] * 1e3:.0f} TF)  "
           f"dgrad {tot['dgrad'] / 1e3:.2f} ms ({tot_fl / tot['dgrad'] * 1e3:.0f} TF)  "
           f"wgrad {tot['wgrad'] / 1e3:.2f} ms ({tot_fl / tot['wgrad'] * 1e3:.0f} TF)  [{tot_fl / 1e3:.2f} TFLOP per pass]")
