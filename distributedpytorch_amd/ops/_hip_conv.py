@@ -81,6 +81,7 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
         cfg = _TUNED.get(key)
         if cfg is None:
             cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device) if _AUTOTUNE else 1
+            _save_tuned()
     if cfg > 0:
         st = _lib().dp_conv_igemm2(*args, cfg, B.stream_ptr())
         if st != -2:       # -2: shape not taken by the second-generation kernel (7x7 stem, bias+stats)
@@ -99,6 +100,22 @@ _FORCED_CFG = int(os.environ["DPAMD_CONV_CFG"]) if "DPAMD_CONV_CFG" in os.enviro
 _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 0)
 _TUNED: dict = {}
+# optional cross-process cache of the measured choices (JSON): set DPAMD_CONV_TUNE_FILE
+_TUNE_FILE = os.environ.get("DPAMD_CONV_TUNE_FILE")
+if _TUNE_FILE and os.path.isfile(_TUNE_FILE):
+    import json as _json
+    with open(_TUNE_FILE) as _f:
+        _TUNED.update({tuple(tuple(v) if isinstance(v, list) else v for v in _json.loads(k)): c
+                       for k, c in _json.load(_f).items()})
+
+
+def _save_tuned() -> None:
+    if _TUNE_FILE:
+        import json
+        tmp = f"{_TUNE_FILE}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump({json.dumps(k): c for k, c in _TUNED.items()}, f)
+        os.replace(tmp, _TUNE_FILE)
 
 
 def _autotune(args, stats, reps, cout, device) -> int:
@@ -156,7 +173,7 @@ def stat_replicas(m_rows: int) -> int:
     return max(1, min(8, tiles // 64))
 
 
-def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None) -> torch.Tensor:
+def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None, splits: int = 0) -> torch.Tensor:
     """dw fp32, logical [Cout,Cin,R,S] stored channels-last (KRSC).  ``out``: accumulate into this
     tensor (the parameter-gradient arena view) instead of a fresh zeroed one."""
     cout, cin, r, s = wshape
@@ -171,7 +188,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None)
         dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
                          memory_format=torch.channels_last).zero_()
     B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
-                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 0, 0, B.stream_ptr()),
+                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, 0, B.stream_ptr()),
             "conv_wgrad")
     return dw
 

@@ -114,11 +114,36 @@ def sweep(args):
           + " ".join(f"{tot_d[c] / 1e3:7.2f}" for c in cfgs) + f" | best-per-layer fwd {best_f / 1e3:.2f} dgrad {best_d / 1e3:.2f}")
 
 
+def sweep_wgrad(args):
+    splits = [int(c) for c in args.splits.split(",")]
+    dev = "cuda"
+    print(f"{'layer':16s} {'cnt':>3s} {'P':>7s} {'Cout':>5s} {'RSC':>6s} | " + " ".join(f"s{c:<6d}" for c in splits))
+    tot = {c: 0.0 for c in splits}
+    for name, cnt, cin, cout, hw, k, stride, pad, dil in R101_DEEPLAB:
+        if args.filter and args.filter not in name:
+            continue
+        n = args.batch
+        ho = (hw + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        cin_p, cout_p = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+        x = torch.randn(n, cin_p, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(n, cout_p, ho, ho, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        out = torch.zeros(cout_p, cin_p, k, k, device=dev).contiguous(memory_format=torch.channels_last)
+        ts = {}
+        for c in splits:
+            ts[c] = timeit(lambda: _hip_conv.wgrad(dy, x, (cout_p, cin_p, k, k), (stride, stride), (pad, pad),
+                                                   (dil, dil), out=out, splits=c))
+            tot[c] += cnt * ts[c]
+        print(f"{name:16s} {cnt:3d} {n * ho * ho:7d} {cout_p:5d} {cin_p * k * k:6d} | "
+              + " ".join(f"{ts[c]:7.1f}" for c in splits), flush=True)
+    print("TOTAL ms" + " " * 35 + " ".join(f"{tot[c] / 1e3:7.2f}" for c in splits))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--stock", action="store_true", help="also time MIOpen through F.conv2d")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--splits", default="", help="comma list of wgrad split-K counts to sweep (0 = auto)")
     ap.add_argument("--cfgs", default="", help="comma list of conv_igemm2 tile configs to sweep (0 = gen-1 kernel)")
     args = ap.parse_args()
     dev = "cuda"
@@ -163,6 +188,9 @@ def main():
         print(line, flush=True)
     if args.cfgs:
         sweep(args)
+        return
+    if args.splits:
+        sweep_wgrad(args)
         return
     print(f"TOTAL weighted: fwd {tot['fwd'] / 1e3:.2f} ms ({tot_fl / tot['fwd'] * 1e3:.0f} TF)  "
           f"dgrad {tot['dgrad'] / 1e3:.2f} ms ({tot_fl / tot['dgrad'] * 1e3:.0f} TF)  "
