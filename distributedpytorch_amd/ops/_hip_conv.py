@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _backend as B
-from . import workspace
+from . import streams, workspace
 from ._hip_bn import as_nhwc
 
 _sigs_done = False
@@ -259,7 +259,15 @@ class _ConvIGemm(torch.autograd.Function):
                     and wp.grad.data_ptr() == sink.data_ptr()):
                 # accumulate straight into the gradient arena (the kernel adds with fp32 atomics):
                 # no temporary, no zero-fill, no AccumulateGrad add; then tell the DDP bucketer
-                wgrad(dy, x, (cout, cin, r, s), stride, padding, dilation, out=sink)
+                if streams.enabled():
+                    # off the critical path: runs beside the dgrad -> BN-backward chain (ops.streams)
+                    aux = streams.fork(dy.device)
+                    with torch.cuda.stream(aux):
+                        wgrad(dy, x, (cout, cin, r, s), stride, padding, dilation, out=sink)
+                    dy.record_stream(aux)
+                    x.record_stream(aux)
+                else:
+                    wgrad(dy, x, (cout, cin, r, s), stride, padding, dilation, out=sink)
                 notify = getattr(wp, "_dpamd_on_grad", None)
                 if notify is not None:
                     notify(wp)

@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from ..ops import streams
 from .arena import ParamArena
 
 
@@ -97,6 +98,8 @@ class DistributedDataParallel(nn.Module):
         if self.world_size == 1:
             return
         g = self.arena.bucket_grad(b)
+        if g.is_cuda:
+            streams.join(g.device)     # weight gradients are produced on the aux stream (ops.streams)
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         self._works.append(work)
         self.stats["buckets_launched"] += 1
@@ -117,6 +120,8 @@ class DistributedDataParallel(nn.Module):
                 self._launch(b)
             for w in self._works:
                 w.wait()
+        if self.arena.flat_g.is_cuda:
+            streams.join(self.arena.flat_g.device)
         self.reset_buckets()
         return 1.0 / self.world_size
 
