@@ -200,6 +200,249 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Second generation (same tile geometry and fragment reads, new load path and pipeline).
+// The ISA of the kernel above shows `s_waitcnt vmcnt(0)` between issue_stage() and the first
+// transposing read of every K-step — hipcc cannot tell the LDS-DMA writes of stage t+1 from the
+// reads of stage t — so its "prefetch" never overlapped anything, and every step paid ~100 VALU of
+// pixel bookkeeping.  Here:
+//   * operands arrive through buffer descriptors (`buffer_load_dwordx4 … lds`): the dy rows need NO
+//     per-step VALU at all (fixed per-lane offset + a wave-uniform SGPR offset that advances by one
+//     pixel block; the descriptor ends at the split's last pixel, so the tail rows read as zeros),
+//     the x rows of 1×1/stride-1 convolutions likewise, and the general x rows keep (ox, oy, n)
+//     incrementally and turn an invalid tap into an out-of-range offset;
+//   * the wait for stage t is an explicit `s_waitcnt vmcnt(0)` placed BEFORE the barrier that opens
+//     step t, the loads of step t+1 are issued right after that barrier and fly under the MFMAs;
+//   * full tiles add their 64 accumulator registers with unconditional atomics (no 64 branches).
+constexpr unsigned kOOBw = 0x80000000u;
+
+struct Wgrad2Args {
+    const bf16_raw* dy; const bf16_raw* x; float* dw;
+    int P, Hi, Wi, Cin, Ho, Wo, Cout, R, S;
+    int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int NF, tiles_k, tiles_n, splits, px_per_split;
+    unsigned x_bytes;
+};
+
+__device__ __forceinline__ void lds_dma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff,
+                                           unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
+                                             soff, 0, 0);
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles = p.tiles_k * p.tiles_n;
+    const int split = bid / tiles;
+    const int tile = bid - split * tiles;
+    const int tile_k = tile % p.tiles_k, tile_n = tile / p.tiles_k;
+    const int k0 = tile_k * TM, n0 = tile_n * TN;
+    const int p_begin = split * p.px_per_split;
+    const int p_end = min(p.P, p_begin + p.px_per_split);
+    const int nsteps = (p_end - p_begin + TP - 1) / TP;
+
+    // descriptors: dy ends at this split's last pixel (tail rows of the last K-step read as zeros)
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p_end * (unsigned)p.Cout * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+
+    const int pc = lane & 15;
+    const int rsub = lane >> 4;
+    const int fsw = (rsub << 2) | wave;
+    const int lc = pc ^ fsw;
+    const int row0 = wave * 4 + rsub;                  // + 16·i for load round i
+
+    // dy operand: channels k0 + lc*8 .. +7 of pixel (p_begin + row)
+    const int kch = k0 + lc * 8;
+    unsigned dy_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        dy_voff[i] = kch < p.Cout ? (unsigned)(((p_begin + i * 16 + row0) * p.Cout + kch) * 2) : kOOBw;
+    const unsigned dy_step = (unsigned)(TP * p.Cout * 2);
+
+    // x operand: flattened weight-row index -> (tap, channel)
+    const int flat = n0 + lc * 8;
+    const bool n_ok = flat < p.NF;
+    const int tap = flat / p.Cin;
+    const int cch = flat - tap * p.Cin;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int tdy = tr * p.dil_h - p.pad_h, tdx = ts * p.dil_w - p.pad_w;
+    unsigned x_voff[4];                                 // UNIT: fixed offsets
+    int pox[4], poy[4], pnb[4];                         // general: pixel state (pnb = n·Hi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = p_begin + i * 16 + row0;
+        if (UNIT) {
+            x_voff[i] = n_ok ? (unsigned)((px * p.Cin + cch) * 2) : kOOBw;
+        } else {
+            pox[i] = px % p.Wo;
+            const int t = px / p.Wo;
+            poy[i] = t % p.Ho;
+            pnb[i] = (t / p.Ho) * p.Hi;
+        }
+    }
+    const unsigned x_step = (unsigned)(TP * p.Cin * 2);
+    const int adv_x = TP % p.Wo, adv_y = TP / p.Wo;
+
+    // The hardware range check looks at the per-lane offset only, so the running pixel offset is kept
+    // in the VGPR offsets (one v_add per load and step) and the SGPR offset stays 0.  An out-of-range
+    // lane starts at 2^31 and the tensors are < 2^31 - 2^24 bytes: it stays out of range, no wrap.
+    auto issue_stage = [&](int buf) {
+        unsigned char* dbase = smem + buf * STAGE + wave * 1024;
+        unsigned char* xbase = dbase + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lds_dma16w(rdy, dbase + i * 4096, dy_voff[i], 0);
+            dy_voff[i] += dy_step;
+        }
+        if (UNIT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lds_dma16w(rx, xbase + i * 4096, x_voff[i], 0);
+                x_voff[i] += x_step;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = poy[i] * p.stride_h + tdy, ix = pox[i] * p.stride_w + tdx;
+                const bool ok = n_ok & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+                // pixels beyond P have n >= N: their offset lies beyond the descriptor and reads zeros
+                const unsigned off = (unsigned)((((pnb[i] + iy) * p.Wi + ix) * p.Cin + cch) * 2);
+                lds_dma16w(rx, xbase + i * 4096, ok ? off : kOOBw, 0);
+                pox[i] += adv_x; poy[i] += adv_y;
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; }
+                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; pnb[i] += p.Hi; }
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int row = 8 * (g >> 1) + 4 * rd + q;
+            const int f = (q << 2) | ((2 * (g >> 1) + rd) & 3);
+            const int chA = ((wm * 64 + t * 32) >> 3) + 2 * (g & 1) + (pp >> 1);
+            const int chB = ((wn * 64 + t * 32) >> 3) + 2 * (g & 1) + (pp >> 1);
+            offA[t][rd] = row * 256 + ((chA ^ f) << 4) + (pp & 1) * 8;
+            offB[t][rd] = row * 256 + ((chB ^ f) << 4) + (pp & 1) * 8;
+        }
+    }
+
+    // Fragment reads are inline asm: hipcc cannot tell an LDS-DMA write from a later LDS read and puts
+    // `s_waitcnt vmcnt(0)` before the first read it KNOWS of, which would drain the stage issued a few
+    // instructions earlier.  The reads' own completion is tracked by hand (counted lgkmcnt, register
+    // sets tied to the wait so the MFMAs cannot move above it).
+    unsigned aA[2][2], aB[2][2];                        // LDS byte addresses (buffer 0)
+    {
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                aA[t][rd] = base + (unsigned)offA[t][rd];
+                aB[t][rd] = base + TILE_BYTES + (unsigned)offB[t][rd];
+            }
+    }
+    s16x4 fa[2][2][2], fb[2][2][2];                     // [set][sub-tile][rd]
+#define WG2_READS(SET, KK)                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                             \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[SET][i_][0]) : "v"(aA[i_][0]), "n"((KK) * 4096)); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[SET][i_][1]) : "v"(aA[i_][1]), "n"((KK) * 4096)); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[SET][i_][0]) : "v"(aB[i_][0]), "n"((KK) * 4096)); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[SET][i_][1]) : "v"(aB[i_][1]), "n"((KK) * 4096)); \
+    }
+#define WG2_WAIT(SET, N)                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                       \
+                 : "+v"(fa[SET][0][0]), "+v"(fa[SET][0][1]), "+v"(fa[SET][1][0]), "+v"(fa[SET][1][1]),             \
+                   "+v"(fb[SET][0][0]), "+v"(fb[SET][0][1]), "+v"(fb[SET][1][0]), "+v"(fb[SET][1][1]))
+#define WG2_MFMA(SET)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {           \
+        typedef __attribute__((ext_vector_type(8))) short s16x8_;                                                  \
+        const s16x8_ va = __builtin_shufflevector(fa[SET][i_][0], fa[SET][i_][1], 0, 1, 2, 3, 4, 5, 6, 7);        \
+        const s16x8_ vb = __builtin_shufflevector(fb[SET][j_][0], fb[SET][j_][1], 0, 1, 2, 3, 4, 5, 6, 7);        \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),                      \
+                                                              __builtin_bit_cast(bf16x8, vb), acc[i_][j_], 0, 0, 0); \
+    }
+
+    unsigned flip = (unsigned)STAGE;
+    if (nsteps > 0) issue_stage(0);
+    for (int t = 0; t < nsteps; ++t) {
+        // stage t landed (vmcnt) and my reads of the other buffer are done (every read is waited for
+        // before the MFMAs that close a step), then everyone's
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nsteps) issue_stage((t & 1) ^ 1);
+        WG2_READS(0, 0)
+        WG2_READS(1, 1)
+        WG2_WAIT(0, 8);
+        WG2_MFMA(0)
+        WG2_READS(0, 2)
+        WG2_WAIT(1, 8);
+        WG2_MFMA(1)
+        WG2_READS(1, 3)
+        WG2_WAIT(0, 8);
+        WG2_MFMA(0)
+        WG2_WAIT(1, 0);
+        WG2_MFMA(1)
+        // flip the fragment addresses to the other buffer
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { aA[a][b] += flip; aB[a][b] += flip; }
+        flip = 0u - flip;
+    }
+#undef WG2_READS
+#undef WG2_WAIT
+#undef WG2_MFMA
+
+    // ---- split-K combine ----
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const bool full = (k0 + TM <= p.Cout) & (n0 + TN <= p.NF);     // uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + frow;
+            float* base = p.dw + (long)(k0 + wm * 64 + i * 32 + 4 * fhalf) * p.NF + col;
+            if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    atomicAdd(base + (long)((e & 3) + 8 * (e >> 2)) * p.NF, acc[i][j][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                    if (row < p.Cout && col < p.NF) atomicAdd(p.dw + (long)row * p.NF + col, acc[i][j][e]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // splits: 0 = auto.  dw must be zero-initialised (or hold a gradient to accumulate into).
@@ -246,6 +489,18 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     p.splits = (int)((P + p.px_per_split - 1) / p.px_per_split);
     const long nwg = (long)tiles * p.splits;
     if (nwg > 0x7fffffffL) return -4;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, p);
+    const long x_bytes = (long)N * Hi * Wi * Cin * 2;
+    if (reserved == 1 || x_bytes >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24)) {
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, p);
+        return DP_LAUNCH_STATUS();
+    }
+    Wgrad2Args q{};
+    q.dy = p.dy; q.x = p.x; q.dw = p.dw; q.P = p.P; q.Hi = Hi; q.Wi = Wi; q.Cin = Cin; q.Ho = Ho; q.Wo = Wo;
+    q.Cout = Cout; q.R = R; q.S = S; q.stride_h = stride_h; q.stride_w = stride_w; q.pad_h = pad_h; q.pad_w = pad_w;
+    q.dil_h = dil_h; q.dil_w = dil_w; q.NF = p.NF; q.tiles_k = p.tiles_k; q.tiles_n = p.tiles_n; q.splits = p.splits;
+    q.px_per_split = p.px_per_split; q.x_bytes = (unsigned)x_bytes;
+    const bool unit = R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1;
+    if (unit) hipLaunchKernelGGL(conv_wgrad2_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
+    else hipLaunchKernelGGL(conv_wgrad2_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
     return DP_LAUNCH_STATUS();
 }

@@ -173,6 +173,10 @@ def stat_replicas(m_rows: int) -> int:
     return max(1, min(8, tiles // 64))
 
 
+# DPAMD_WGRAD_GEN=1 selects the first-generation weight-gradient kernel (A/B runs, bisection)
+_WGRAD_GEN1 = 1 if os.environ.get("DPAMD_WGRAD_GEN", "2") == "1" else 0
+
+
 def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None, splits: int = 0) -> torch.Tensor:
     """dw fp32, logical [Cout,Cin,R,S] stored channels-last (KRSC).  ``out``: accumulate into this
     tensor (the parameter-gradient arena view) instead of a fresh zeroed one."""
@@ -188,7 +192,8 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
         dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
                          memory_format=torch.channels_last).zero_()
     B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
-                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, 0, B.stream_ptr()),
+                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, _WGRAD_GEN1,
+                                 B.stream_ptr()),
             "conv_wgrad")
     return dw
 

@@ -21,7 +21,13 @@ from typing import Dict, Optional
 import torch
 
 _ENABLED = os.environ.get("DPAMD_AUX_STREAM", "1") != "0"
-_streams: Dict[int, "torch.cuda.Stream"] = {}
+# Number of auxiliary streams used round-robin.  A weight-gradient kernel ends in a burst of fp32
+# atomics (its split-K combine); the next kernel of the SAME stream cannot start until that burst has
+# drained, a kernel of another stream can.  Measured at B32 (gpurun_out/s8_bench_b32_aux*.log): 697 img/s
+# with one aux stream, 685 with two, so one is the default; GPU_MAX_HW_QUEUES is 4 (main + comm + 2 aux).
+_NAUX = max(1, int(os.environ.get("DPAMD_AUX_STREAMS", "1")))
+_streams: Dict[int, list] = {}
+_next: Dict[int, int] = {}
 _dirty: Dict[int, bool] = {}
 
 
@@ -35,11 +41,15 @@ def set_enabled(flag: bool) -> None:
 
 
 def aux_stream(device: Optional[torch.device] = None) -> "torch.cuda.Stream":
+    """The next auxiliary stream of ``device`` (round-robin over DPAMD_AUX_STREAMS streams)."""
     idx = torch.cuda.current_device() if device is None or device.index is None else device.index
-    st = _streams.get(idx)
-    if st is None:
-        st = _streams[idx] = torch.cuda.Stream(device=idx)
-    return st
+    pool = _streams.get(idx)
+    if pool is None:
+        pool = _streams[idx] = [torch.cuda.Stream(device=idx) for _ in range(_NAUX)]
+        _next[idx] = 0
+    k = _next[idx]
+    _next[idx] = (k + 1) % len(pool)
+    return pool[k]
 
 
 def fork(device: Optional[torch.device] = None) -> "torch.cuda.Stream":
@@ -54,5 +64,7 @@ def join(device: Optional[torch.device] = None) -> None:
     """Make the current stream wait for all work enqueued on the aux stream."""
     idx = torch.cuda.current_device() if device is None or device.index is None else device.index
     if _dirty.get(idx):
-        torch.cuda.current_stream(idx).wait_stream(_streams[idx])
+        cur = torch.cuda.current_stream(idx)
+        for st in _streams[idx]:
+            cur.wait_stream(st)
         _dirty[idx] = False

@@ -139,6 +139,36 @@ def test_igemm2_all_tile_configs(case, cfg):
     assert _rel(dx, xr.grad) < 1.5e-2
 
 
+WGRAD_CASES = [
+    # n, cin, cout, h, w, k, stride, pad, dil
+    (3, 64, 128, 33, 31, 1, 1, 0, 1),       # 1x1 fast path, pixel tail (3069 = 47*64 + 61)
+    (2, 72, 200, 19, 19, 1, 1, 0, 1),       # Cout / Cin tails of the 128x128 tile
+    (2, 64, 136, 33, 33, 3, 1, 2, 2),       # taps straddle tiles (NF = 576), dilation
+    (2, 128, 64, 35, 33, 3, 2, 1, 1),       # strided
+    (3, 256, 64, 9, 9, 3, 1, 12, 12),       # halo larger than the map
+    (2, 64, 64, 21, 23, 1, 2, 0, 1),        # 1x1 stride 2 (general path with one tap)
+]
+
+
+@pytest.mark.parametrize("splits", [0, 1, 3, 5])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_splits(case, splits):
+    """csrc/conv_wgrad.hip: forced split-K counts (tail splits, one split) against an fp32 CPU
+    weight gradient; also accumulation into a pre-filled gradient buffer."""
+    from distributedpytorch_amd.ops import _hip_conv
+    n, cin, cout, h, w, k, stride, pad, dil = case
+    torch.manual_seed(5)
+    x = _bf(torch.randn(n, cin, h, w, device=DEV))
+    wr = torch.zeros(cout, cin, k, k, requires_grad=True)
+    yr = F.conv2d(x.float().cpu(), wr, None, stride, pad, dil)
+    gy = _bf(torch.randn_like(yr))
+    yr.backward(gy.float())
+    out = torch.ones(cout, cin, k, k, device=DEV).contiguous(memory_format=torch.channels_last)
+    dw = _hip_conv.wgrad(_nhwc(gy.to(DEV)), _nhwc(x), (cout, cin, k, k), (stride, stride), (pad, pad), (dil, dil),
+                         out=out, splits=splits)
+    assert _rel(dw - 1.0, wr.grad) < 1e-2
+
+
 @pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
 def test_depthwise(stride, dil):
     torch.manual_seed(1)
