@@ -33,8 +33,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DPAMD_BENCH_BATCH", "16")),
-                    help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DPAMD_BENCH_BATCH", "64")),
+                    help="per-GPU batch (64 x 513² holds 28 GiB of the 288 GB HBM3E)")
     ap.add_argument("--crop", type=int, default=513)
     ap.add_argument("--model", default="deeplabv3plus_resnet101")
     ap.add_argument("--output-stride", type=int, default=None)
@@ -48,6 +48,11 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # hang watchdog: DPAMD_HANG_DUMP_S=N dumps every thread's Python stack to stderr
+    # and exits if the run is still going after N seconds — a stuck collective names its call site
+    if os.environ.get("DPAMD_HANG_DUMP_S"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DPAMD_HANG_DUMP_S"]), exit=True)
     from distributedpytorch_amd import ops
     from distributedpytorch_amd.models import build_model
     from distributedpytorch_amd.ops import SoftmaxCrossEntropy, affine_augment, make_affine_params

@@ -68,8 +68,12 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_raw* __restrict__ 
 // ----------------------------------------- max-pool -----------------------------------------
 struct Pool { int N, C, Hi, Wi, Ho, Wo; };
 
+// forward also records, per output element, WHICH of the 9 taps was the (first, row-major) maximum:
+// one byte, 8 channels = one 8-byte store.  Backward then never touches x: an input pixel looks at
+// the <= 4 windows covering it and takes dy where the recorded tap is its own (ATen's tie rule, and
+// 6 loads per thread instead of ~40 — the first version spent 754 us per step here).
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_raw* __restrict__ x, bf16_raw* __restrict__ y,
-                                                          Pool p) {
+                                                          unsigned char* __restrict__ idx, Pool p) {
     const int C8 = p.C >> 3;
     const long total = (long)p.N * p.Ho * p.Wo * C8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -79,8 +83,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_raw* __rest
         const int oy = (int)(pix % p.Ho);
         const int n = (int)(pix / p.Ho);
         float best[8];
+        unsigned code[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) best[j] = -3.0e38f;
+        for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; code[j] = 4; }
         for (int r = 0; r < 3; ++r) {
             const int iy = oy * 2 - 1 + r;
             if (iy < 0 || iy >= p.Hi) continue;
@@ -90,18 +95,22 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_raw* __rest
                 float f[8];
                 unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cg * 8), f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], f[j]);
+                for (int j = 0; j < 8; ++j)
+                    if (f[j] > best[j]) { best[j] = f[j]; code[j] = (unsigned)(r * 3 + s); }
             }
         }
-        *reinterpret_cast<uint4*>(y + (((long)n * p.Ho + oy) * p.Wo + ox) * p.C + cg * 8) = pack8(best);
+        const long o = (((long)n * p.Ho + oy) * p.Wo + ox) * p.C + cg * 8;
+        *reinterpret_cast<uint4*>(y + o) = pack8(best);
+        uint2 pk;
+        pk.x = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+        pk.y = code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24);
+        *reinterpret_cast<uint2*>(idx + o) = pk;
     }
 }
 
-// dx[i] = Σ over windows o covering i of dy[o]·[i is the FIRST arg-max of window o] (ATen tie rule)
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_raw* __restrict__ dy,
-                                                          const bf16_raw* __restrict__ x,
-                                                          const bf16_raw* __restrict__ y, bf16_raw* __restrict__ dx,
-                                                          Pool p) {
+                                                          const unsigned char* __restrict__ idx,
+                                                          bf16_raw* __restrict__ dx, Pool p) {
     const int C8 = p.C >> 3;
     const long total = (long)p.N * p.Hi * p.Wi * C8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -110,39 +119,24 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_raw* __rest
         const int ix = (int)(pix % p.Wi); pix /= p.Wi;
         const int iy = (int)(pix % p.Hi);
         const int n = (int)(pix / p.Hi);
-        float xv[8], acc[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cg * 8), xv);
+        float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
-        const int oy_lo = max(0, (iy) / 2), oy_hi = min(p.Ho - 1, (iy + 1) / 2);
-        const int ox_lo = max(0, (ix) / 2), ox_hi = min(p.Wo - 1, (ix + 1) / 2);
+        const int oy_lo = iy / 2, oy_hi = min(p.Ho - 1, (iy + 1) / 2);
+        const int ox_lo = ix / 2, ox_hi = min(p.Wo - 1, (ix + 1) / 2);
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                float yv[8], dv[8];
+                const unsigned mine = (unsigned)((iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1)));
                 const long o = (((long)n * p.Ho + oy) * p.Wo + ox) * p.C + cg * 8;
-                unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
+                const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+                float dv[8];
                 unpack8(*reinterpret_cast<const uint4*>(dy + o), dv);
-                // is an EARLIER element of this window also equal to the max?  (row-major scan order)
-                bool earlier[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) earlier[j] = false;
-                for (int r = 0; r < 3; ++r) {
-                    const int yy = oy * 2 - 1 + r;
-                    if (yy < 0 || yy >= p.Hi) continue;
-                    for (int s = 0; s < 3; ++s) {
-                        const int xx = ox * 2 - 1 + s;
-                        if (xx < 0 || xx >= p.Wi) continue;
-                        if (yy > iy || (yy == iy && xx >= ix)) continue;
-                        float f[8];
-                        unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * p.Hi + yy) * p.Wi + xx) * p.C + cg * 8), f);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) earlier[j] = earlier[j] || (f[j] == yv[j]);
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned cj = ((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xffu;
+                    if (cj == mine) acc[j] += dv[j];
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (xv[j] == yv[j] && !earlier[j]) acc[j] += dv[j];
             }
         }
         *reinterpret_cast<uint4*>(dx + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cg * 8) = pack8(acc);
@@ -312,21 +306,21 @@ DP_EXPORT int dp_scale_bf16(void* x, long n, const float* s, hipStream_t st) {
     return DP_LAUNCH_STATUS();
 }
 
-DP_EXPORT int dp_maxpool3x3s2_fwd(const void* x, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
+DP_EXPORT int dp_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int N, int C, int Hi, int Wi, int Ho, int Wo,
                                   hipStream_t st) {
     if (C % 8 != 0 || Ho != (Hi + 2 - 3) / 2 + 1 || Wo != (Wi + 2 - 3) / 2 + 1) return -1;
     Pool p{N, C, Hi, Wi, Ho, Wo};
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_1d((long)N * Ho * Wo * (C / 8), 256)), dim3(256), 0, st,
-                       (const bf16_raw*)x, (bf16_raw*)y, p);
+                       (const bf16_raw*)x, (bf16_raw*)y, (unsigned char*)idx, p);
     return DP_LAUNCH_STATUS();
 }
 
-DP_EXPORT int dp_maxpool3x3s2_bwd(const void* dy, const void* x, const void* y, void* dx, int N, int C, int Hi,
+DP_EXPORT int dp_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int N, int C, int Hi,
                                   int Wi, int Ho, int Wo, hipStream_t st) {
     if (C % 8 != 0 || Ho != (Hi + 2 - 3) / 2 + 1 || Wo != (Wi + 2 - 3) / 2 + 1) return -1;
     Pool p{N, C, Hi, Wi, Ho, Wo};
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_1d((long)N * Hi * Wi * (C / 8), 256)), dim3(256), 0, st,
-                       (const bf16_raw*)dy, (const bf16_raw*)x, (const bf16_raw*)y, (bf16_raw*)dx, p);
+                       (const bf16_raw*)dy, (const unsigned char*)idx, (bf16_raw*)dx, p);
     return DP_LAUNCH_STATUS();
 }
 

@@ -113,11 +113,17 @@ class DeepLabV3Plus(nn.Module):
         self.aspp = ASPP(self.backbone.out_channels, output_stride)
         self.decoder = Decoder(self.backbone.low_level_channels, num_classes)
         self.num_classes = num_classes
+        # When set (by the training engine, for a criterion that upsamples inside the loss kernel:
+        # ops.loss / csrc/upsample_ce.hip) the training forward returns the stride-4 logits and the
+        # 513² map is never written; evaluation always returns full-resolution logits.
+        self.defer_upsample = False
 
     def forward(self, x):
         size = x.shape[2:]
         feat, low = self.backbone(x)
         y = self.decoder(self.aspp(feat), low)
+        if self.defer_upsample and self.training:
+            return y
         return bilinear_resize(y, size)
 
     # parameter groups named as in /root/reference/train_pascal.py:90-91

@@ -29,10 +29,14 @@ class FCN(nn.Module):
         self.backbone = ResNet(backbone, output_stride, in_channels, multi_grid=None)
         self.head = FCNHead(self.backbone.out_channels, num_classes)
         self.num_classes = num_classes
+        self.defer_upsample = False
 
     def forward(self, x):
         feat, _ = self.backbone(x)
-        return bilinear_resize(self.head(feat, self.training), x.shape[2:])
+        y = self.head(feat, self.training)
+        if self.defer_upsample and self.training:
+            return y      # the criterion upsamples inside the loss kernel (see DeepLabV3Plus)
+        return bilinear_resize(y, x.shape[2:])
 
     def get_1x_lr_params(self):
         return (p for p in self.backbone.parameters() if p.requires_grad)

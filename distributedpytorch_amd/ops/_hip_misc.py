@@ -19,12 +19,14 @@ def _lib():
         V, I, L, F = c_void_p, c_int, c_long, c_float
         lib.dp_softmax_ce_fwd.argtypes = [V, V, I, L, I, I, V, V]
         lib.dp_softmax_ce_bwd.argtypes = [V, V, I, L, I, I, V, V, V, V]
+        lib.dp_upsample_ce_fwd.argtypes = [V, V, I, I, I, I, I, I, I, I, I, V, V]
+        lib.dp_upsample_ce_bwd.argtypes = [V, V, I, I, I, I, I, I, I, I, I, I, V, V, V, V]
         lib.dp_bilinear_fwd.argtypes = [V, V, I, I, I, I, I, I, V]
         lib.dp_bilinear_bwd.argtypes = [V, V, I, I, I, I, I, I, V]
         lib.dp_sgd_flat.argtypes = [V, V, V, V, L, F, F, F, F, I, I, V]
         lib.dp_scale_bf16.argtypes = [V, L, V, V]
-        lib.dp_maxpool3x3s2_fwd.argtypes = [V, V, I, I, I, I, I, I, V]
-        lib.dp_maxpool3x3s2_bwd.argtypes = [V, V, V, V, I, I, I, I, I, I, V]
+        lib.dp_maxpool3x3s2_fwd.argtypes = [V, V, V, I, I, I, I, I, I, V]
+        lib.dp_maxpool3x3s2_bwd.argtypes = [V, V, V, I, I, I, I, I, I, V]
         lib.dp_gap_fwd.argtypes = [V, V, I, I, I, V]
         lib.dp_gap_bwd.argtypes = [V, V, I, I, I, V]
         lib.dp_affine_augment.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V, V, V]
@@ -78,6 +80,49 @@ def softmax_ce_bwd(logits, target, ignore_index, sums, gloss):
     return dlogits
 
 
+# ------------------------------------------------------------------ fused upsample + softmax CE
+def _strided_nhwc(t: torch.Tensor):
+    """(tensor, ld): ``t`` [N,C,H,W] bf16 whose memory is NHWC with a channel stride ld >= C — a
+    channels-last tensor (ld = C) or the ``[:, :C]`` view of one (the classifier's padded output)."""
+    if t.dtype != torch.bfloat16 or t.dim() != 4:
+        raise TypeError("upsample_ce: logits must be bf16 [N,C,H,W]")
+    n, c, h, w = t.shape
+    ld = t.stride(3)
+    if not (t.stride(1) == 1 and ld >= c and t.stride(2) == w * ld and t.stride(0) == h * w * ld):
+        t = as_nhwc(t)
+        ld = c
+    return t, ld
+
+
+def upsample_ce_fwd(logits: torch.Tensor, target: torch.Tensor, ignore_index: int):
+    """Σloss / #valid of CE(bilinear_align_corners(logits → target size), target) without
+    materialising the upsampled logits.  Returns None when the shape is not taken (caller falls back)."""
+    x, ld = _strided_nhwc(logits)
+    n, c, hi, wi = x.shape
+    ho, wo = target.shape[1:]
+    target, kind = _label(target, (n, ho, wo))
+    sums = torch.zeros(2, dtype=torch.float32, device=x.device)
+    st = _lib().dp_upsample_ce_fwd(B.ptr(x), B.ptr(target), kind, n, c, ld, hi, wi, ho, wo, int(ignore_index),
+                                   B.ptr(sums), B.stream_ptr())
+    if st == -2:
+        return None
+    B.check(st, "upsample_ce_fwd")
+    return sums[0] / sums[1].clamp_min(1.0), sums, x, target, ld
+
+
+def upsample_ce_bwd(x, ld, target, ignore_index, sums, gloss):
+    n, c, hi, wi = x.shape
+    ho, wo = target.shape[1:]
+    kind = _LABEL_KIND[target.dtype]
+    g = gloss.detach().reshape(1).float().contiguous()
+    ldo = (c + 7) // 8 * 8
+    dx = torch.empty((n, ldo, hi, wi), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_upsample_ce_bwd(B.ptr(x), B.ptr(target), kind, n, c, ld, ldo, hi, wi, ho, wo,
+                                      int(ignore_index), B.ptr(sums), B.ptr(g), B.ptr(dx), B.stream_ptr()),
+            "upsample_ce_bwd")
+    return dx[:, :c] if ldo != c else dx
+
+
 # ------------------------------------------------------------------ bilinear
 def bilinear_fwd(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
     x = _req_bf16_nhwc(x, "x")
@@ -99,24 +144,27 @@ def bilinear_bwd(dy: torch.Tensor, in_size: Tuple[int, int]) -> torch.Tensor:
 
 # ------------------------------------------------------------------ pooling
 def maxpool3x3s2_fwd(x):
+    """Returns (y, idx): idx holds, per output element, the 3x3 tap (0..8) that was the maximum."""
     x = _req_bf16_nhwc(x, "x")
     n, c, hi, wi = x.shape
     if c % 8:
         raise ValueError("max-pool kernel needs C % 8 == 0")
     ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
     y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    B.check(_lib().dp_maxpool3x3s2_fwd(B.ptr(x), B.ptr(y), n, c, hi, wi, ho, wo, B.stream_ptr()), "maxpool_fwd")
-    return y
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    B.check(_lib().dp_maxpool3x3s2_fwd(B.ptr(x), B.ptr(y), B.ptr(idx), n, c, hi, wi, ho, wo, B.stream_ptr()),
+            "maxpool_fwd")
+    return y, idx
 
 
-def maxpool3x3s2_bwd(dy, x, y):
+def maxpool3x3s2_bwd(dy, idx, in_shape):
     dy = _req_bf16_nhwc(dy, "dy")
-    n, c, hi, wi = x.shape
-    ho, wo = y.shape[2:]
-    if dy.shape != y.shape:
-        raise ValueError("dy/y shape mismatch")
-    dx = torch.empty_like(x)
-    B.check(_lib().dp_maxpool3x3s2_bwd(B.ptr(dy), B.ptr(x), B.ptr(y), B.ptr(dx), n, c, hi, wi, ho, wo,
+    n, c, hi, wi = in_shape
+    ho, wo = dy.shape[2:]
+    if tuple(idx.shape) != (n, ho, wo, c) or idx.dtype != torch.uint8 or not idx.is_contiguous():
+        raise ValueError("maxpool_bwd: idx must be the uint8 [N,Ho,Wo,C] map written by the forward")
+    dx = torch.empty((n, c, hi, wi), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_maxpool3x3s2_bwd(B.ptr(dy), B.ptr(idx), B.ptr(dx), n, c, hi, wi, ho, wo,
                                        B.stream_ptr()), "maxpool_bwd")
     return dx
 

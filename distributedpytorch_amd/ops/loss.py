@@ -32,8 +32,48 @@ class _SoftmaxCEHip(torch.autograd.Function):
         return _hip_misc.softmax_ce_bwd(logits, target, ctx.ignore_index, sums, gloss), None, None
 
 
+class _UpsampleCEHip(torch.autograd.Function):
+    """CE(bilinear(logits → label size), labels) in one pass each way (csrc/upsample_ce.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        from . import _hip_misc
+        r = _hip_misc.upsample_ce_fwd(logits, target, ignore_index)
+        if r is None:
+            raise NotImplementedError("fused upsample+CE: shape not taken")
+        loss, sums, x, target_c, ld = r
+        ctx.save_for_backward(x, target_c, sums)
+        ctx.ld = ld
+        ctx.ignore_index = ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        from . import _hip_misc
+        x, target, sums = ctx.saved_tensors
+        return _hip_misc.upsample_ce_bwd(x, ctx.ld, target, ctx.ignore_index, sums, gloss), None, None
+
+
+def _fused_upsample_ok(logits, target) -> bool:
+    c, hi, wi = logits.shape[1:]
+    ho, wo = target.shape[1:]
+    # the kernels' LDS carve (see dp_upsample_ce_fwd/_bwd): upsampling only, a bounded footprint
+    if ho < hi or wo < wi or c > 64:
+        return False
+    fh = int(5 * (ho - 1) / max(hi - 1, 1)) + 2 if hi > 1 else ho
+    fw = int(9 * (wo - 1) / max(wi - 1, 1)) + 2 if wi > 1 else wo
+    return 60 * c * 4 + (fh + fw) * 8 + fh * fw * c * 2 <= 64 * 1024 and 9 * 33 * c * 4 <= 60 * 1024
+
+
 def softmax_cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = 255) -> torch.Tensor:
-    """Mean CE over non-ignored pixels.  ``logits`` [N,C,H,W], ``target`` [N,H,W] integer."""
+    """Mean CE over non-ignored pixels.  ``logits`` [N,C,H,W], ``target`` [N,H',W'] integer.  When
+    the label map is larger than the logits, the loss is that of the logits bilinearly upsampled
+    (align_corners=True) to the label size — the DeepLab head — computed without materialising them."""
+    if tuple(logits.shape[2:]) != tuple(target.shape[1:]):
+        if B.use_hip(logits) and _fused_upsample_ok(logits, target):
+            return _UpsampleCEHip.apply(logits, target, ignore_index)
+        from .upsample import bilinear_resize
+        logits = bilinear_resize(logits, tuple(target.shape[1:]))
     if B.use_hip(logits):
         return _SoftmaxCEHip.apply(logits, target, ignore_index)
     # same convention as the kernel: Σ loss / max(valid pixels, 1) — an all-ignored batch gives 0, not NaN
@@ -43,6 +83,9 @@ def softmax_cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_ind
 
 
 class SoftmaxCrossEntropy(nn.Module):
+    # the engine lets models that can skip their final upsample do so (``defer_upsample``)
+    fuses_upsample = True
+
     def __init__(self, ignore_index: int = 255):
         super().__init__()
         self.ignore_index = ignore_index

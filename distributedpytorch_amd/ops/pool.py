@@ -14,15 +14,16 @@ class _MaxPool3x3s2Hip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         from . import _hip_misc
-        y = _hip_misc.maxpool3x3s2_fwd(x)
-        ctx.save_for_backward(x, y)
+        y, idx = _hip_misc.maxpool3x3s2_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.in_shape = tuple(x.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import _hip_misc
-        x, y = ctx.saved_tensors
-        return _hip_misc.maxpool3x3s2_bwd(dy, x, y)
+        (idx,) = ctx.saved_tensors
+        return _hip_misc.maxpool3x3s2_bwd(dy, idx, ctx.in_shape)
 
 
 class _GlobalAvgPoolHip(torch.autograd.Function):

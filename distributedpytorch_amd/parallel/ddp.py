@@ -21,12 +21,29 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional, Sequence
 
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 from ..ops import streams
 from .arena import ParamArena
+
+
+_DEBUG = os.environ.get("DPAMD_DDP_DEBUG", "0") != "0"
+# DPAMD_DDP_SYNC=1: blocking bucket all-reduces (no overlap) — a bisection knob
+_SYNC = os.environ.get("DPAMD_DDP_SYNC", "0") != "0"
+# DPAMD_DDP_FORCE=1: run the whole communication path (broadcast, bucket all-reduces, waits) even in
+# a 1-rank group — rehearses the RCCL stream/event choreography on a single GPU
+_FORCE = os.environ.get("DPAMD_DDP_FORCE", "0") != "0"
+
+
+def _dbg(msg: str) -> None:
+    if _DEBUG:
+        r = dist.get_rank() if dist.is_initialized() else 0
+        print(f"[ddp r{r}] {msg}", file=sys.stderr, flush=True)
 
 
 def _world(group=None) -> int:
@@ -55,7 +72,8 @@ class DistributedDataParallel(nn.Module):
         self._next = 0
         self._sync_enabled = True
         self.stats = {"buckets_launched": 0, "bytes_reduced": 0}
-        if self.world_size > 1:
+        self._comm = self.world_size > 1 or (_FORCE and dist.is_initialized())
+        if self._comm:
             self._broadcast_initial_state(broadcast_buffers)
         self._install_hooks()
         self.reset_buckets()
@@ -66,8 +84,19 @@ class DistributedDataParallel(nn.Module):
         dist.broadcast(self.arena.flat_p, src=0, group=self.process_group)
         self.arena.refresh_lowp()
         if broadcast_buffers:
+            # BN running statistics / counters: one flat message per dtype, not ~300 tiny ones
+            by_dtype: dict = {}
             for buf in self.module.buffers():
-                dist.broadcast(buf, src=0, group=self.process_group)
+                if buf.numel():
+                    by_dtype.setdefault(buf.dtype, []).append(buf)
+            for bufs in by_dtype.values():
+                flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+                dist.broadcast(flat, src=0, group=self.process_group)
+                off = 0
+                with torch.no_grad():
+                    for b in bufs:
+                        b.copy_(flat[off:off + b.numel()].view_as(b))
+                        off += b.numel()
 
     def _install_hooks(self) -> None:
         for si, slot in enumerate(self.arena.slots):
@@ -95,13 +124,15 @@ class DistributedDataParallel(nn.Module):
             self._next += 1
 
     def _launch(self, b: int) -> None:
-        if self.world_size == 1:
+        if not self._comm:
             return
         g = self.arena.bucket_grad(b)
         if g.is_cuda:
             streams.join(g.device)     # weight gradients are produced on the aux stream (ops.streams)
-        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
-        self._works.append(work)
+        _dbg(f"launch bucket {b} numel {g.numel()}")
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=not _SYNC)
+        if work is not None:
+            self._works.append(work)
         self.stats["buckets_launched"] += 1
         self.stats["bytes_reduced"] += g.numel() * 4
 
@@ -118,7 +149,8 @@ class DistributedDataParallel(nn.Module):
         if self._sync_enabled:
             for b in range(self._next, len(self.arena.buckets)):
                 self._launch(b)
-            for w in self._works:
+            for i, w in enumerate(self._works):
+                _dbg(f"wait work {i}/{len(self._works)}")
                 w.wait()
         if self.arena.flat_g.is_cuda:
             streams.join(self.arena.flat_g.device)

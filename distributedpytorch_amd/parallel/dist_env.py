@@ -46,8 +46,11 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 600,
     else:
         dev = torch.device("cpu")
     if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
-    if world > 1 and not dist.is_initialized():
+        # DPAMD_DIST_BACKEND=gloo: run the GPU ranks over gloo (rehearsal of the multi-rank GPU path on
+        # a box with fewer GPUs than ranks; RCCL refuses two ranks on one device)
+        backend = os.environ.get("DPAMD_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+    force = os.environ.get("DPAMD_DDP_FORCE", "0") != "0"   # 1-rank process group (see parallel.ddp)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # xGMI / dmabuf IPC requirement of this platform (see task environment notes)
@@ -57,7 +60,7 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 600,
         if backend == "nccl":
             kwargs["device_id"] = dev
         dist.init_process_group(**kwargs)
-    return DistInfo(rank, local_rank, world, backend if world > 1 else "none", dev)
+    return DistInfo(rank, local_rank, world, backend if (world > 1 or force) else "none", dev)
 
 
 def shutdown() -> None:

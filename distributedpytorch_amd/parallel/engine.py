@@ -53,6 +53,8 @@ class TrainEngine:
                                            process_group=process_group)
         self.model = model
         self.criterion = criterion
+        if getattr(criterion, "fuses_upsample", False) and hasattr(model, "defer_upsample"):
+            model.defer_upsample = True
         self.optimizer = FlatSGD(self.ddp.arena, [lr * m for m in mults], momentum, weight_decay)
         self.accum_steps = max(int(accum_steps), 1)
         self._micro = 0

@@ -299,6 +299,43 @@ def test_softmax_ce(c, hw):
     assert float(z) == 0.0 and float(lh2.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("c,hin,hout,padded", [(21, (129, 129), (513, 513), True), (21, (33, 17), (129, 65), False),
+                                               (7, (17, 17), (33, 33), False), (21, (33, 33), (100, 77), True),
+                                               (21, (17, 17), (129, 129), False), (3, (1, 1), (4, 4), False)])
+def test_upsample_ce_fused(c, hin, hout, padded):
+    """csrc/upsample_ce.hip: CE of the bilinearly upsampled logits, loss and gradient, against
+    F.interpolate(align_corners=True) + F.cross_entropy in fp32.  (17 -> 129 is outside the fused
+    kernels' footprint budget and runs the unfused pair through the same entry point.)"""
+    torch.manual_seed(11)
+    n = 2
+    base = _bf(torch.randn(n, c, *hin, device=DEV) * 3)
+    t = torch.randint(0, c, (n, *hout), device=DEV)
+    t[:, : max(hout[0] // 7, 1)] = 255
+    t[0, -1, -1] = 255
+    xr = base.float().cpu().requires_grad_(True)
+    up = F.interpolate(xr, size=hout, mode="bilinear", align_corners=True)
+    lr = F.cross_entropy(up, t.cpu(), ignore_index=255)
+    (lr * 1.7).backward()
+    if padded:   # the classifier's output: a [:, :c] view of a channel-padded NHWC buffer
+        cp = (c + 7) // 8 * 8
+        buf = torch.full((n, cp, *hin), 9.0, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        buf[:, :c] = base
+        xh = buf[:, :c].detach().requires_grad_(True)
+    else:
+        xh = _nhwc(base).requires_grad_(True)
+    for tt in (t, t.to(torch.uint8)):
+        xh.grad = None
+        lh = ops.softmax_cross_entropy(xh, tt, 255)
+        (lh * 1.7).backward()
+        assert abs(float(lh) - float(lr)) < 2e-3 * max(1.0, abs(float(lr)))
+        assert _rel(xh.grad, xr.grad) < 1.5e-2
+    # all-ignored batch: loss 0, gradient 0
+    xh.grad = None
+    lz = ops.softmax_cross_entropy(xh, torch.full_like(t, 255), 255)
+    lz.backward()
+    assert float(lz) == 0.0 and float(xh.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("c,hin,hout", [(256, 33, 129), (21, 129, 513), (48, 17, 65), (21, 33, 20), (64, 1, 9)])
 def test_bilinear(c, hin, hout):
     torch.manual_seed(5)
