@@ -44,56 +44,85 @@ __device__ __forceinline__ int ld_label(const void* p, long i) {
     return (int)reinterpret_cast<const LabelT*>(p)[i];
 }
 
-template <typename LabelT>
+// CMAX: compile-time bound on C so a pixel's interpolated logits live in registers (one exp per
+// class instead of the online softmax's two, one pass over the LDS taps); 0 = generic loop.
+template <typename LabelT, int CMAX>
 __global__ __launch_bounds__(kT) void upsample_ce_fwd_kernel(UpCeArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* tile = reinterpret_cast<float*>(smem_raw);           // [FF_H][FF_W][C]
     __shared__ float red[2 * (kT / kWave)];
     const int tid = threadIdx.x;
-    int b = blockIdx.x;
-    const int tx = b % p.tiles_x; b /= p.tiles_x;
-    const int ty = b % p.tiles_y;
-    const int n = b / p.tiles_y;
-    const int oy0 = ty * FT_H, ox0 = tx * FT_W;
-    const int oy_last = min(oy0 + FT_H, p.Ho) - 1, ox_last = min(ox0 + FT_W, p.Wo) - 1;
-    const int ylo = min((int)(oy0 * p.ry), p.Hi - 1), xlo = min((int)(ox0 * p.rx), p.Wi - 1);
-    const int yhi = min(min((int)(oy_last * p.ry), p.Hi - 1) + 1, p.Hi - 1);
-    const int xhi = min(min((int)(ox_last * p.rx), p.Wi - 1) + 1, p.Wi - 1);
-    const int fh = min(yhi - ylo + 1, FF_H), fw = min(xhi - xlo + 1, FF_W);
     const int C = p.C;
-    // stage the footprint: rows are contiguous runs of fw pixels
-    const int per_row = fw * C;
-    for (int e = tid; e < fh * per_row; e += kT) {
-        const int r = e / per_row, rem = e - r * per_row;
-        const int xx = rem / C, c = rem - xx * C;
-        tile[(r * FF_W + xx) * C + c] =
-            bf2f(p.x[(((long)n * p.Hi + ylo + r) * p.Wi + xlo + xx) * p.ld + c]);
-    }
-    __syncthreads();
-    const int oy = oy0 + tid / FT_W, ox = ox0 + tid % FT_W;
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
     float loss = 0.f, cnt = 0.f;
-    if (oy < p.Ho && ox < p.Wo) {
-        const int t = ld_label<LabelT>(p.target, ((long)n * p.Ho + oy) * p.Wo + ox);
-        if (t != p.ignore_index && t >= 0 && t < C) {
-            const float sy = oy * p.ry, sx = ox * p.rx;
-            const int y0 = min((int)sy, p.Hi - 1), x0 = min((int)sx, p.Wi - 1);
-            const int y1 = min(y0 + 1, p.Hi - 1), x1 = min(x0 + 1, p.Wi - 1);
-            const float fy = sy - y0, fx = sx - x0;
-            const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
-            const float* t00 = tile + (min(y0 - ylo, FF_H - 1) * FF_W + min(x0 - xlo, FF_W - 1)) * C;
-            const float* t01 = tile + (min(y0 - ylo, FF_H - 1) * FF_W + min(x1 - xlo, FF_W - 1)) * C;
-            const float* t10 = tile + (min(y1 - ylo, FF_H - 1) * FF_W + min(x0 - xlo, FF_W - 1)) * C;
-            const float* t11 = tile + (min(y1 - ylo, FF_H - 1) * FF_W + min(x1 - xlo, FF_W - 1)) * C;
-            float m = -3.0e38f, s = 0.f, vt = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float v = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
-                if (c == t) vt = v;
-                const float mn = fmaxf(m, v);
-                s = s * __expf(m - mn) + __expf(v - mn);
-                m = mn;
+    // persistent: a block walks tiles and leaves ONE atomic pair behind (35k same-address atomics
+    // serialise into ~0.6 ms otherwise)
+    for (int b0 = blockIdx.x; b0 < ntiles; b0 += gridDim.x) {
+        int b = b0;
+        const int tx = b % p.tiles_x; b /= p.tiles_x;
+        const int ty = b % p.tiles_y;
+        const int n = b / p.tiles_y;
+        const int oy0 = ty * FT_H, ox0 = tx * FT_W;
+        const int oy_last = min(oy0 + FT_H, p.Ho) - 1, ox_last = min(ox0 + FT_W, p.Wo) - 1;
+        const int ylo = min((int)(oy0 * p.ry), p.Hi - 1), xlo = min((int)(ox0 * p.rx), p.Wi - 1);
+        const int yhi = min(min((int)(oy_last * p.ry), p.Hi - 1) + 1, p.Hi - 1);
+        const int xhi = min(min((int)(ox_last * p.rx), p.Wi - 1) + 1, p.Wi - 1);
+        const int fh = min(yhi - ylo + 1, FF_H), fw = min(xhi - xlo + 1, FF_W);
+        __syncthreads();                                         // previous tile's readers are done
+        // stage the footprint: every row is one contiguous run of fw*ld elements in memory
+        {
+            const int run = (fw - 1) * p.ld + C;                 // elements of a row that matter
+            for (int r = 0; r < fh; ++r) {
+                const bf16_raw* src = p.x + (((long)n * p.Hi + ylo + r) * p.Wi + xlo) * p.ld;
+                for (int e = tid; e < run; e += kT) {
+                    const int xx = e / p.ld, c = e - xx * p.ld;
+                    if (c < C) tile[(r * FF_W + xx) * C + c] = bf2f(src[e]);
+                }
             }
-            loss = __logf(s) + m - vt;
-            cnt = 1.f;
+        }
+        __syncthreads();
+        const int oy = oy0 + tid / FT_W, ox = ox0 + tid % FT_W;
+        if (oy < p.Ho && ox < p.Wo) {
+            const int t = ld_label<LabelT>(p.target, ((long)n * p.Ho + oy) * p.Wo + ox);
+            if (t != p.ignore_index && t >= 0 && t < C) {
+                const float sy = oy * p.ry, sx = ox * p.rx;
+                const int y0 = min((int)sy, p.Hi - 1), x0 = min((int)sx, p.Wi - 1);
+                const int y1 = min(y0 + 1, p.Hi - 1), x1 = min(x0 + 1, p.Wi - 1);
+                const float fy = sy - y0, fx = sx - x0;
+                const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
+                const float* t00 = tile + (min(y0 - ylo, FF_H - 1) * FF_W + min(x0 - xlo, FF_W - 1)) * C;
+                const float* t01 = tile + (min(y0 - ylo, FF_H - 1) * FF_W + min(x1 - xlo, FF_W - 1)) * C;
+                const float* t10 = tile + (min(y1 - ylo, FF_H - 1) * FF_W + min(x0 - xlo, FF_W - 1)) * C;
+                const float* t11 = tile + (min(y1 - ylo, FF_H - 1) * FF_W + min(x1 - xlo, FF_W - 1)) * C;
+                if (CMAX > 0) {
+                    float v[CMAX > 0 ? CMAX : 1];
+                    float m = -3.0e38f, vt = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < C) {
+                            v[c] = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
+                            m = fmaxf(m, v[c]);
+                            if (c == t) vt = v[c];
+                        }
+                    }
+                    float ssum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (c < C) ssum += __expf(v[c] - m);
+                    loss += __logf(ssum) + m - vt;
+                } else {
+                    float m = -3.0e38f, ssum = 0.f, vt = 0.f;
+                    for (int c = 0; c < C; ++c) {
+                        const float v = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
+                        if (c == t) vt = v;
+                        const float mn = fmaxf(m, v);
+                        ssum = ssum * __expf(m - mn) + __expf(v - mn);
+                        m = mn;
+                    }
+                    loss += __logf(ssum) + m - vt;
+                }
+                cnt += 1.f;
+            }
         }
     }
     loss = wave_sum(loss);
@@ -116,7 +145,7 @@ __global__ __launch_bounds__(kT) void upsample_ce_fwd_kernel(UpCeArgs p) {
 __device__ __forceinline__ int fp_lo(int i, float inv_r) { return (int)floorf((i - 1) * inv_r + 1e-3f) + 1; }
 __device__ __forceinline__ int fp_hi(int i, float inv_r) { return (int)ceilf((i + 1) * inv_r - 1e-3f) - 1; }
 
-template <typename LabelT>
+template <typename LabelT, int CMAX>
 __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int C = p.C;
@@ -125,7 +154,9 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
     float* yfr = reinterpret_cast<float*>(ytab + p.FH);                  // [FH]: fy
     int* xtab = reinterpret_cast<int*>(yfr + p.FH);                      // [FW]
     float* xfr = reinterpret_cast<float*>(xtab + p.FW);                  // [FW]
-    bf16_raw* g = reinterpret_cast<bf16_raw*>(xfr + p.FW);               // [FH][FW][C]
+    float* wyt = xfr + p.FW;                                             // [BT_H][FH]: weight of footprint row j for tile row r
+    float* wxt = wyt + BT_H * p.FH;                                      // [BT_W][FW]
+    bf16_raw* g = reinterpret_cast<bf16_raw*>(wxt + BT_W * p.FW);        // [FH][FW][C]
     const int tid = threadIdx.x;
     int b = blockIdx.x;
     const int tx = b % p.tiles_x; b /= p.tiles_x;
@@ -140,22 +171,45 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
     const int fh = min(oy_hi - oy_lo + 1, p.FH), fw = min(ox_hi - ox_lo + 1, p.FW);
     const float k = p.gloss[0] / fmaxf(p.sums[1], 1.f);
 
-    // low-res logits around the tile (clamped at the image border), tap tables
-    for (int e = tid; e < (BT_H + 2) * (BT_W + 2) * C; e += kT) {
-        const int pix = e / C, c = e - pix * C;
-        const int r = pix / (BT_W + 2), q = pix - r * (BT_W + 2);
-        const int y = min(max(iy0 - 1 + r, 0), p.Hi - 1), x = min(max(ix0 - 1 + q, 0), p.Wi - 1);
-        lr[e] = bf2f(p.x[(((long)n * p.Hi + y) * p.Wi + x) * p.ld + c]);
+    // low-res logits around the tile (clamped at the image border): rows are contiguous runs
+    {
+        const int run = (BT_W + 2) * C;
+        for (int r = 0; r < BT_H + 2; ++r) {
+            const int y = min(max(iy0 - 1 + r, 0), p.Hi - 1);
+            const bf16_raw* src = p.x + ((long)n * p.Hi + y) * p.Wi * p.ld;
+            for (int e = tid; e < run; e += kT) {
+                const int q = e / C, c = e - q * C;
+                const int x = min(max(ix0 - 1 + q, 0), p.Wi - 1);
+                lr[r * run + e] = bf2f(src[(long)x * p.ld + c]);
+            }
+        }
     }
+    // tap tables and the per-(tile row, footprint row) / (tile col, footprint col) weights
     for (int j = tid; j < fh; j += kT) {
         const float sy = (oy_lo + j) * p.ry;
-        const int y0 = min((int)sy, p.Hi - 1);
-        ytab[j] = y0; yfr[j] = sy - y0;
+        const int y0 = min((int)sy, p.Hi - 1), y1 = min(y0 + 1, p.Hi - 1);
+        const float fy = sy - y0;
+        ytab[j] = y0; yfr[j] = fy;
+#pragma unroll
+        for (int r = 0; r < BT_H; ++r) {
+            float w = 0.f;
+            if (y0 == iy0 + r) w += 1.f - fy;
+            if (y1 == iy0 + r) w += fy;
+            wyt[r * p.FH + j] = w;
+        }
     }
     for (int j = tid; j < fw; j += kT) {
         const float sx = (ox_lo + j) * p.rx;
-        const int x0 = min((int)sx, p.Wi - 1);
-        xtab[j] = x0; xfr[j] = sx - x0;
+        const int x0 = min((int)sx, p.Wi - 1), x1 = min(x0 + 1, p.Wi - 1);
+        const float fx = sx - x0;
+        xtab[j] = x0; xfr[j] = fx;
+#pragma unroll
+        for (int q = 0; q < BT_W; ++q) {
+            float w = 0.f;
+            if (x0 == ix0 + q) w += 1.f - fx;
+            if (x1 == ix0 + q) w += fx;
+            wxt[q * p.FW + j] = w;
+        }
     }
     __syncthreads();
 
@@ -175,19 +229,36 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
             const float* t01 = lr + (ry0 * (BT_W + 2) + rx1) * C;
             const float* t10 = lr + (ry1 * (BT_W + 2) + rx0) * C;
             const float* t11 = lr + (ry1 * (BT_W + 2) + rx1) * C;
-            float m = -3.0e38f, s = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float v = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
-                const float mn = fmaxf(m, v);
-                s = s * __expf(m - mn) + __expf(v - mn);
-                m = mn;
-            }
-            const float inv = k / s;
-            for (int c = 0; c < C; ++c) {
-                const float v = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
-                float pr = __expf(v - m) * inv;
-                if (c == t) pr -= k;
-                gp[c] = f2bf(pr);
+            if (CMAX > 0) {
+                float v[CMAX > 0 ? CMAX : 1];
+                float m = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) {
+                        v[c] = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
+                        m = fmaxf(m, v[c]);
+                    }
+                float ssum = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) { v[c] = __expf(v[c] - m); ssum += v[c]; }
+                const float inv = k / ssum;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) gp[c] = f2bf(v[c] * inv - (c == t ? k : 0.f));
+            } else {
+                float m = -3.0e38f, ssum = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float v = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
+                    const float mn = fmaxf(m, v);
+                    ssum = ssum * __expf(m - mn) + __expf(v - mn);
+                    m = mn;
+                }
+                const float inv = k / ssum;
+                for (int c = 0; c < C; ++c) {
+                    const float v = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
+                    gp[c] = f2bf(__expf(v - m) * inv - (c == t ? k : 0.f));
+                }
             }
         } else {
             for (int c = 0; c < C; ++c) gp[c] = 0;
@@ -206,23 +277,13 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
             int jl = 0, jh = fh - 1, il = 0, ih = fw - 1;
             if (p.ry > 0.f) { jl = max(fp_lo(iy, inv_ry) - oy_lo, 0); jh = min(fp_hi(iy, inv_ry) - oy_lo, fh - 1); }
             if (p.rx > 0.f) { il = max(fp_lo(ix, inv_rx) - ox_lo, 0); ih = min(fp_hi(ix, inv_rx) - ox_lo, fw - 1); }
+            const float* wy = wyt + r * p.FH;
+            const float* wx = wxt + q * p.FW;
             for (int j = jl; j <= jh; ++j) {
-                const int y0 = ytab[j], y1 = min(y0 + 1, p.Hi - 1);
-                const float fy = yfr[j];
-                float wy = 0.f;
-                if (y0 == iy) wy += 1.f - fy;
-                if (y1 == iy) wy += fy;
-                if (wy == 0.f) continue;
+                const bf16_raw* grow = g + ((long)j * fw) * C + c;
                 float rowacc = 0.f;
-                for (int i = il; i <= ih; ++i) {
-                    const int x0 = xtab[i], x1 = min(x0 + 1, p.Wi - 1);
-                    const float fx = xfr[i];
-                    float wx = 0.f;
-                    if (x0 == ix) wx += 1.f - fx;
-                    if (x1 == ix) wx += fx;
-                    rowacc = fmaf(wx, bf2f(g[((long)j * fw + i) * C + c]), rowacc);
-                }
-                acc = fmaf(wy, rowacc, acc);
+                for (int i = il; i <= ih; ++i) rowacc = fmaf(wx[i], bf2f(grow[i * C]), rowacc);
+                acc = fmaf(wy[j], rowacc, acc);
             }
         }
         p.dx[(((long)n * p.Hi + iy) * p.Wi + ix) * p.ldo + c] = f2bf(acc);
@@ -248,9 +309,14 @@ DP_EXPORT int dp_upsample_ce_fwd(const void* x, const void* target, int label_ki
     if (lds > 60 * 1024) return -2;
     p.x = (const bf16_raw*)x; p.target = target; p.sums = sums;
     p.tiles_y = (Ho + FT_H - 1) / FT_H; p.tiles_x = (Wo + FT_W - 1) / FT_W;
-    const long grid = (long)N * p.tiles_y * p.tiles_x;
-    if (grid > 0x7fffffffL) return -2;
-#define LAUNCH(T) hipLaunchKernelGGL(upsample_ce_fwd_kernel<T>, dim3((unsigned)grid), dim3(kT), lds, st, p)
+    const long tiles = (long)N * p.tiles_y * p.tiles_x;
+    if (tiles > 0x7fffffffL) return -2;
+    const long grid = tiles < 2048 ? tiles : 2048;       // persistent: 8 blocks per CU
+#define LAUNCH(T)                                                                                              \
+    do {                                                                                                       \
+        if (C <= 32) hipLaunchKernelGGL((upsample_ce_fwd_kernel<T, 32>), dim3((unsigned)grid), dim3(kT), lds, st, p); \
+        else hipLaunchKernelGGL((upsample_ce_fwd_kernel<T, 0>), dim3((unsigned)grid), dim3(kT), lds, st, p);   \
+    } while (0)
     if (label_kind == 0) LAUNCH(unsigned char);
     else if (label_kind == 1) LAUNCH(int);
     else LAUNCH(long long);
@@ -267,6 +333,7 @@ DP_EXPORT int dp_upsample_ce_bwd(const void* x, const void* target, int label_ki
     p.FH = p.ry > 0.f ? (int)((BT_H + 1) / p.ry) + 2 : Ho;
     p.FW = p.rx > 0.f ? (int)((BT_W + 1) / p.rx) + 2 : Wo;
     const size_t lds = (size_t)(BT_H + 2) * (BT_W + 2) * C * sizeof(float) + (size_t)(p.FH + p.FW) * 8 +
+                       (size_t)(BT_H * p.FH + BT_W * p.FW) * sizeof(float) +
                        (size_t)p.FH * p.FW * C * sizeof(bf16_raw);
     if (lds > 64 * 1024) return -2;
     p.x = (const bf16_raw*)x; p.target = target; p.sums = const_cast<float*>(sums); p.gloss = gloss;
@@ -274,7 +341,11 @@ DP_EXPORT int dp_upsample_ce_bwd(const void* x, const void* target, int label_ki
     p.tiles_y = (Hi + BT_H - 1) / BT_H; p.tiles_x = (Wi + BT_W - 1) / BT_W;
     const long grid = (long)N * p.tiles_y * p.tiles_x;
     if (grid > 0x7fffffffL) return -2;
-#define LAUNCH(T) hipLaunchKernelGGL(upsample_ce_bwd_kernel<T>, dim3((unsigned)grid), dim3(kT), lds, st, p)
+#define LAUNCH(T)                                                                                              \
+    do {                                                                                                       \
+        if (C <= 32) hipLaunchKernelGGL((upsample_ce_bwd_kernel<T, 32>), dim3((unsigned)grid), dim3(kT), lds, st, p); \
+        else hipLaunchKernelGGL((upsample_ce_bwd_kernel<T, 0>), dim3((unsigned)grid), dim3(kT), lds, st, p);   \
+    } while (0)
     if (label_kind == 0) LAUNCH(unsigned char);
     else if (label_kind == 1) LAUNCH(int);
     else LAUNCH(long long);

@@ -62,7 +62,8 @@ def _fused_upsample_ok(logits, target) -> bool:
         return False
     fh = int(5 * (ho - 1) / max(hi - 1, 1)) + 2 if hi > 1 else ho
     fw = int(9 * (wo - 1) / max(wi - 1, 1)) + 2 if wi > 1 else wo
-    return 60 * c * 4 + (fh + fw) * 8 + fh * fw * c * 2 <= 64 * 1024 and 9 * 33 * c * 4 <= 60 * 1024
+    return (60 * c * 4 + (fh + fw) * 8 + (4 * fh + 8 * fw) * 4 + fh * fw * c * 2 <= 64 * 1024
+            and 9 * 33 * c * 4 <= 60 * 1024)
 
 
 def softmax_cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = 255) -> torch.Tensor:
