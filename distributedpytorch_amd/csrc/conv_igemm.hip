@@ -295,6 +295,47 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const bf16_raw* _
     }
 }
 
+// All layers at once (one launch per optimiser step instead of one per convolution in backward):
+// `table` holds, per weight tensor, {element offset in the arena, K, R, S, C, first tile}; a block
+// transposes one 32(k) x 32(c) tile of one filter tap through LDS, so both the reads (c contiguous)
+// and the writes (k contiguous) are coalesced.  src and dst arenas share offsets.
+struct WtSlot { long off; int K, R, S, C; int tile0; int tiles_k; };
+
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const bf16_raw* __restrict__ src,
+                                                                       bf16_raw* __restrict__ dst,
+                                                                       const WtSlot* __restrict__ table, int nslots) {
+    __shared__ bf16_raw tile[32][33];
+    const int b = blockIdx.x;
+    int lo = 0, hi = nslots - 1;                 // last slot with tile0 <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const WtSlot sl = table[lo];
+    int t = b - sl.tile0;
+    const int tk = t % sl.tiles_k; t /= sl.tiles_k;
+    const int tiles_c = (sl.C + 31) >> 5;
+    const int tc = t % tiles_c;
+    const int tap = t / tiles_c;                  // r*S + s
+    const int r = tap / sl.S, s2 = tap - r * sl.S;
+    const int tapT = (sl.R - 1 - r) * sl.S + (sl.S - 1 - s2);
+    const int taps = sl.R * sl.S;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;      // 32 x 8
+    const bf16_raw* w = src + sl.off;
+    bf16_raw* wt = dst + sl.off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tk * 32 + ly + i * 8, c = tc * 32 + lx;
+        tile[ly + i * 8][lx] = (k < sl.K && c < sl.C) ? w[((long)k * taps + tap) * sl.C + c] : (bf16_raw)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tc * 32 + ly + i * 8, k = tk * 32 + lx;
+        if (k < sl.K && c < sl.C) wt[((long)c * taps + tapT) * sl.K + k] = tile[lx][ly + i * 8];
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int SDIV>
 int launch(ConvArgs& p, hipStream_t st) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -342,5 +383,15 @@ DP_EXPORT int dp_weight_transpose(const void* w, void* wt, int K, int R, int S, 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_raw*)w,
                        (bf16_raw*)wt, K, R, S, C);
+    return DP_LAUNCH_STATUS();
+}
+
+// table: device array of nslots records {int64 off; int32 K, R, S, C, tile0, tiles_k} (32 bytes each)
+DP_EXPORT int dp_weight_transpose_batched(const void* src, void* dst, const void* table, int nslots, int total_tiles,
+                                          hipStream_t st) {
+    if (nslots <= 0 || total_tiles <= 0) return 0;
+    static_assert(sizeof(WtSlot) == 32, "table record layout");
+    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st,
+                       (const bf16_raw*)src, (bf16_raw*)dst, (const WtSlot*)table, nslots);
     return DP_LAUNCH_STATUS();
 }

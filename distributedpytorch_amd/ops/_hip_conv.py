@@ -31,6 +31,7 @@ def _lib():
         lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
+        lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
@@ -167,6 +168,18 @@ def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
     return wt
 
 
+def weight_transpose_batched(src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, nslots: int,
+                             total_tiles: int) -> None:
+    """Every dense conv weight of the bf16 arena ``src`` -> tap-flipped Cin<->Cout transposed copy at the
+    same offsets of ``dst`` (parallel.arena).  ``table``: uint8 view of the 32-byte slot records."""
+    if src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16 or src.numel() != dst.numel():
+        raise TypeError("weight_transpose_batched: bf16 arenas of equal size")
+    if table.dtype != torch.uint8 or table.numel() != 32 * nslots or not table.is_contiguous():
+        raise ValueError("weight_transpose_batched: table must be nslots 32-byte records")
+    B.check(_lib().dp_weight_transpose_batched(B.ptr(src), B.ptr(dst), B.ptr(table), nslots, total_tiles,
+                                               B.stream_ptr()), "weight_transpose_batched")
+
+
 def stat_replicas(m_rows: int) -> int:
     """Replica count for the fused-statistics accumulators: ~one replica per 64 M-tiles, ≤ 8."""
     tiles = (m_rows + 127) // 128
@@ -207,6 +220,7 @@ class _ConvIGemm(torch.autograd.Function):
         wo = _out_size(wi, s, stride[1], padding[1], dilation[1])
         if stride[0] != stride[1]:
             raise NotImplementedError("anisotropic stride")
+        ctx.set_materialize_grads(False)     # no zero-fill launch for the statistics output's "gradient"
         x = as_nhwc(x)
         cin_p, cout_p = _round8(cin), _round8(cout)
         w_used = w_lowp
@@ -242,6 +256,8 @@ class _ConvIGemm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *unused):
+        if dy is None:
+            return (None,) * 8
         x, w_used = ctx.saved_tensors
         stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p = ctx.geom
         if cout_p != cout:
@@ -252,7 +268,14 @@ class _ConvIGemm(torch.autograd.Function):
         dy = as_nhwc(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight_transpose(w_used)
+            wp = ctx.weight_param
+            wt = getattr(wp, "_dpamd_lowpT", None)
+            # the arena's transposed copy mirrors its bf16 copy (refreshed together after the optimiser
+            # step); anything else (padded channels, out-of-band weight edits) transposes here
+            if not (wt is not None and getattr(wp, "_dpamd_lowpT_ok", False)
+                    and w_used.data_ptr() == getattr(wp, "_dpamd_lowp", w_used).data_ptr()
+                    and getattr(wp, "_dpamd_lowp", None) is not None):
+                wt = weight_transpose(w_used)
             pad_t = (dilation[0] * (r - 1) - padding[0], dilation[1] * (s - 1) - padding[1])
             dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation)
             if cin_p != cin:

@@ -91,6 +91,7 @@ class Conv2d(nn.Module):
                 with torch.no_grad():
                     arena_copy.copy_(w.detach())
                 w._dpamd_lowp_version = w._version
+                w._dpamd_lowpT_ok = False      # backward re-transposes this layer itself
             return arena_copy
         if (self._lowp is None or self._lowp_version != w._version or self._lowp.dtype != dtype
                 or self._lowp.device != w.device):

@@ -97,6 +97,7 @@ class ParamArena:
                 self.flat_lowp.copy_(self.flat_p)
                 for s in self.slots:
                     s.param._dpamd_lowp_version = s.param._version
+        self._init_transposed()
         # ---- buckets: contiguous slot runs of ~bucket_bytes ----
         self.buckets: List[Bucket] = []
         cap = max(bucket_bytes // 4, 1)
@@ -133,6 +134,56 @@ class ParamArena:
                 self.flat_lowp.copy_(self.flat_p)
             for s in self.slots:
                 s.param._dpamd_lowp_version = s.param._version
+        self.refresh_transposed()
+
+    # ------------------------------------------------------------------
+    # Data-gradient weights.  conv dgrad runs the forward kernel on the tap-flipped, Cin<->Cout
+    # transposed weights; building that copy per layer inside backward costs a launch per convolution
+    # on the critical path (113 for DeepLabv3+ R101).  The arena keeps a third bf16 buffer with the
+    # same offsets and refreshes ALL of it with one kernel right after the optimiser step.
+    def _init_transposed(self) -> None:
+        self.flat_lowpT = None
+        self._wt_table = None
+        if self.flat_lowp is None or self.flat_lowp.dtype != torch.bfloat16 or not self.flat_lowp.is_cuda:
+            return
+        import numpy as np
+        recs, tile0 = [], 0
+        dense = []
+        for s in self.slots:
+            p = s.param
+            if p.dim() == 4 and p.shape[1] > 1 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0:
+                k, c, r, sw = p.shape
+                tiles_k = (k + 31) // 32
+                recs.append((s.offset, k, r, sw, c, tile0, tiles_k))
+                tile0 += r * sw * tiles_k * ((c + 31) // 32)
+                dense.append(s)
+        if not recs:
+            return
+        tab = np.zeros(len(recs), dtype=np.dtype([("off", "<i8"), ("K", "<i4"), ("R", "<i4"), ("S", "<i4"),
+                                                  ("C", "<i4"), ("tile0", "<i4"), ("tiles_k", "<i4")]))
+        for i, rec in enumerate(recs):
+            tab[i] = rec
+        self._wt_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+        self._wt_n, self._wt_tiles = len(recs), tile0
+        self.flat_lowpT = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+        for s in dense:
+            k, c, r, sw = s.param.shape
+            seg = self.flat_lowpT[s.offset:s.offset + s.numel]
+            # logical [Cin, Cout, R, S] stored channels-last = memory [c][r][s][k]
+            s.param._dpamd_lowpT = seg.view(c, r, sw, k).permute(0, 3, 1, 2)
+            s.param._dpamd_lowpT_ok = False
+        self._wt_dense = dense
+        self.refresh_transposed()
+
+    def refresh_transposed(self) -> None:
+        if getattr(self, "flat_lowpT", None) is None:
+            return
+        from ..ops import _backend as B
+        from ..ops import _hip_conv
+        _hip_conv.weight_transpose_batched(self.flat_lowp, self.flat_lowpT, self._wt_table, self._wt_n,
+                                           self._wt_tiles)
+        for s in self._wt_dense:
+            s.param._dpamd_lowpT_ok = True
 
     def rebind(self) -> None:
         """Re-attach ``.data``/``.grad`` views (after ``load_state_dict(assign=True)`` or ``.to()``)."""

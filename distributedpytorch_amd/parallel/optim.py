@@ -45,6 +45,7 @@ class FlatSGD:
                            pg["lr"], pg["momentum"], pg["weight_decay"], grad_scale,
                            zero_grad, first_step=(self._steps == 0))
         self._steps += 1
+        a.refresh_transposed()      # dgrad weights of every conv, one launch (no-op off the HIP path)
         if a.flat_lowp is not None and not a.flat_p.is_cuda:
             for s in a.slots:  # CPU path updated masters through torch ops (version bump)
                 s.param._dpamd_lowp_version = s.param._version

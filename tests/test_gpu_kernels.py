@@ -464,3 +464,32 @@ def test_engine_trains():
     for _ in range(15):
         last = float(eng.train_step(x, y))
     assert math.isfinite(last) and last < first
+
+
+def test_batched_weight_transpose_matches_per_layer():
+    """parallel.arena keeps tap-flipped, Cin<->Cout transposed bf16 weights for the data-gradient
+    (csrc/conv_igemm.hip weight_transpose_batched_kernel): equal to the per-layer transpose, before
+    and after an optimiser step."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy, _hip_conv
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(0)
+    model = build_model("deeplabv3plus_resnet18", 21)
+    eng = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.01, device=torch.device(DEV))
+
+    def check():
+        n = 0
+        for p in model.parameters():
+            wt = getattr(p, "_dpamd_lowpT", None)
+            if wt is None:
+                continue
+            assert p._dpamd_lowpT_ok
+            ref = _hip_conv.weight_transpose(p._dpamd_lowp)
+            assert wt.shape == ref.shape and torch.equal(wt.contiguous(memory_format=torch.channels_last), ref)
+            n += 1
+        assert n > 20
+    check()
+    x = torch.randn(2, 3, 65, 65, device=DEV)
+    y = torch.randint(0, 21, (2, 65, 65), device=DEV)
+    eng.train_step(x, y)
+    check()
