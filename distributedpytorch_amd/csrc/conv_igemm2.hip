@@ -38,6 +38,8 @@ struct Conv2Args {
     bf16_raw* y;            // [M, ldy]
     const float* bias;      // [Cout] or null
     float* stats;           // [stat_reps, 2, Cout] or null (never together with bias)
+    const bf16_raw* res;    // [M, ldres] or null: added to the output in the store loop (the skip-path
+    int ldres;              //   gradient of a residual block joins the data gradient here, no add kernel)
     int stat_reps;
     int M;
     int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
@@ -311,7 +313,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             if (m < p.M && gcol < p.Cout) {
                 const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
                 const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
-                *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                if (p.res) {
+                    float a[8], b[8];
+                    unpack8(o, a);
+                    unpack8(*reinterpret_cast<const uint4*>(p.res + (long)m * p.ldres + gcol), b);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] += b[j];
+                    o = pack8(a);
+                }
+                *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = o;
             }
         }
     }
@@ -354,9 +365,24 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
 //      10 = 256x128 8-wave 2-stage
 // Returns -2 for shapes this kernel does not take (R*S > 32, bias together with stats, Cout % 8):
 // the caller then uses conv_igemm.hip.
+DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
+                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
+                              int sdiv, int pad_h, int pad_w, int dil_h, int dil_w, int ldy, int cfg,
+                              const void* res, int ldres, hipStream_t st);
+
 DP_EXPORT int dp_conv_igemm2(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
                              int sdiv, int pad_h, int pad_w, int dil_h, int dil_w, int ldy, int cfg, hipStream_t st) {
+    return dp_conv_igemm2r(x, w, y, bias, stats, stat_reps, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv, pad_h,
+                           pad_w, dil_h, dil_w, ldy, cfg, nullptr, 0, st);
+}
+
+// + res: optional [N*Ho*Wo, ldres] bf16 tensor added to the output (not part of the fused statistics)
+DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
+                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
+                              int sdiv, int pad_h, int pad_w, int dil_h, int dil_w, int ldy, int cfg,
+                              const void* res, int ldres, hipStream_t st) {
+    if (res && (ldres < Cout || ldres % 8 != 0 || ((uintptr_t)res & 15) || stats)) return -1;
     if (Cin % 8 != 0 || Cin <= 0 || Cout <= 0 || N <= 0 || Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return -1;
     if (ldy < Cout || R <= 0 || S <= 0 || smul < 1 || (sdiv != 1 && sdiv != 2 && sdiv != 4)) return -1;
     if (R * S > 32 || (bias && stats) || Cout % 8 != 0 || ldy % 8 != 0) return -2;
@@ -367,6 +393,7 @@ DP_EXPORT int dp_conv_igemm2(const void* x, const void* w, void* y, const float*
         return -4;
     Conv2Args p{};
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.y = (bf16_raw*)y; p.bias = bias; p.stats = stats;
+    p.res = (const bf16_raw*)res; p.ldres = ldres;
     p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
     p.M = (int)((long)N * Ho * Wo);
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;

@@ -45,8 +45,12 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        if self.downsample is None:
+            # identity routed through conv1's autograd node: its gradient joins conv1's dgrad kernel
+            out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True)
+        else:
+            identity = self.downsample(x)
+            out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity)
 
 
@@ -65,8 +69,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        if self.downsample is None:
+            # identity routed through conv1's autograd node: its gradient joins conv1's dgrad kernel
+            out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True)
+        else:
+            identity = self.downsample(x)
+            out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         out = conv_bn_act(self.conv2, self.bn2, out, relu=True)
         return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity)
 

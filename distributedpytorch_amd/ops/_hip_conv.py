@@ -30,6 +30,7 @@ def _lib():
         V, I = c_void_p, c_int
         lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
+        lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -50,9 +51,11 @@ def _round8(c: int) -> int:
 
 def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
           pad: Tuple[int, int], dil: Tuple[int, int], bias: Optional[torch.Tensor] = None,
-          stats: Optional[torch.Tensor] = None, tile: int = 0, cfg: Optional[int] = None) -> torch.Tensor:
+          stats: Optional[torch.Tensor] = None, tile: int = 0, cfg: Optional[int] = None,
+          residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw kernel call.  ``x`` [N,Cin,Hi,Wi] channels-last bf16; ``w_krsc`` logical [Cout,Cin,R,S]
-    stored channels-last (memory [Cout][R][S][Cin]).  Returns [N,Cout,Ho,Wo] channels-last bf16."""
+    stored channels-last (memory [Cout][R][S][Cin]).  Returns [N,Cout,Ho,Wo] channels-last bf16.
+    ``residual`` (same shape/layout as the result) is added in the kernel's store loop."""
     n, cin, hi, wi = x.shape
     cout, cin_w, r, s = w_krsc.shape
     if x.dtype != torch.bfloat16 or w_krsc.dtype != torch.bfloat16:
@@ -83,12 +86,21 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
         if cfg is None:
             cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device) if _AUTOTUNE else 1
             _save_tuned()
+    if residual is not None:
+        if (residual.dtype != torch.bfloat16 or residual.shape != y.shape or stats is not None
+                or not residual.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("igemm: residual must be a channels-last bf16 tensor of the output's shape (no stats)")
     if cfg > 0:
-        st = _lib().dp_conv_igemm2(*args, cfg, B.stream_ptr())
+        if residual is not None:
+            st = _lib().dp_conv_igemm2r(*args, cfg, B.ptr(residual), cout, B.stream_ptr())
+        else:
+            st = _lib().dp_conv_igemm2(*args, cfg, B.stream_ptr())
         if st != -2:       # -2: shape not taken by the second-generation kernel (7x7 stem, bias+stats)
             B.check(st, "conv_igemm2")
             return y
     B.check(_lib().dp_conv_igemm(*args, tile, B.stream_ptr()), "conv_igemm")
+    if residual is not None:
+        y += residual
     return y
 
 
@@ -213,7 +225,10 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
 
 class _ConvIGemm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation, with_stats=False):
+    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation, with_stats=False, passthrough=False):
+        """``passthrough``: additionally return ``x`` itself as the LAST output.  A residual block
+        routes its skip connection through it, so the skip-path gradient arrives in THIS backward
+        and is added inside the data-gradient kernel instead of by a separate add kernel."""
         cout, cin, r, s = weight.shape
         n, _, hi, wi = x.shape
         ho = _out_size(hi, r, stride[0], padding[0], dilation[0])
@@ -247,17 +262,24 @@ class _ConvIGemm(torch.autograd.Function):
         ctx.geom = (stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p)
         ctx.has_bias = bias is not None
         ctx.weight_param = weight
+        ctx.with_stats, ctx.passthrough = with_stats, passthrough
         if cout_p != cout:
             y = y[:, :cout]
+        outs = [y]
         if with_stats:
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y
+            outs.append(stats)
+        if passthrough:
+            if cin_p != cin:
+                raise ValueError("passthrough needs Cin % 8 == 0")
+            outs.append(x.view_as(x))
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, dy, *unused):
+    def backward(ctx, dy, *rest):
+        dskip = rest[-1] if ctx.passthrough else None
         if dy is None:
-            return (None,) * 8
+            return (dskip,) + (None,) * 8
         x, w_used = ctx.saved_tensors
         stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p = ctx.geom
         if cout_p != cout:
@@ -277,9 +299,13 @@ class _ConvIGemm(torch.autograd.Function):
                     and getattr(wp, "_dpamd_lowp", None) is not None):
                 wt = weight_transpose(w_used)
             pad_t = (dilation[0] * (r - 1) - padding[0], dilation[1] * (s - 1) - padding[1])
-            dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation)
+            if dskip is not None:
+                dskip = as_nhwc(dskip)
+            dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation, residual=dskip)
             if cin_p != cin:
                 dx = dx[:, :cin]
+        elif dskip is not None:
+            dx = dskip
         if ctx.needs_input_grad[1]:
             wp = ctx.weight_param
             sink = getattr(wp, "_dpamd_grad_sink", None)
@@ -305,7 +331,7 @@ class _ConvIGemm(torch.autograd.Function):
                     dw = dw[:cout, :cin]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(dim=(0, 2, 3))[:cout]
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class _DepthwiseConv(torch.autograd.Function):
@@ -346,13 +372,15 @@ class _DepthwiseConv(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False):
+def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False, passthrough=False):
     if x.dtype != torch.bfloat16:
         raise TypeError(f"HIP conv path needs bf16 activations, got {x.dtype}")
     if w_lowp is None:
         w_lowp = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if groups == 1:
-        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats)
+        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats, passthrough)
+    if passthrough:
+        raise NotImplementedError("passthrough is a dense-convolution feature")
     if with_stats:
         raise NotImplementedError("fused statistics are only produced by the dense implicit-GEMM kernel")
     if groups == x.shape[1] == weight.shape[0] and weight.shape[1] == 1:

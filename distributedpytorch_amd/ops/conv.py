@@ -37,7 +37,7 @@ def conv_out_size(n: int, k: int, s: int, p: int, d: int) -> int:
 # --------------------------------------------------------------------------------------
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            stride: _IntOr2 = 1, padding: _IntOr2 = 0, dilation: _IntOr2 = 1, groups: int = 1,
-           w_lowp: Optional[torch.Tensor] = None, with_stats: bool = False):
+           w_lowp: Optional[torch.Tensor] = None, with_stats: bool = False, passthrough: bool = False):
     """2-D convolution.  ``w_lowp`` is an optional up-to-date bf16 KRSC copy of ``weight``.
 
     ``with_stats`` (GPU, dense conv only) additionally returns the per-channel ``[R, 2, Cout]``
@@ -45,12 +45,14 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     if B.use_hip(x):
         from . import _hip_conv
-        return _hip_conv.conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats)
+        return _hip_conv.conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats,
+                                passthrough)
     if with_stats:
         raise ValueError("with_stats is a GPU-kernel feature")
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = None if bias is None else bias.to(x.dtype)
-    return F.conv2d(x, w, b, stride, padding, dilation, groups)
+    y = F.conv2d(x, w, b, stride, padding, dilation, groups)
+    return (y, x) if passthrough else y
 
 
 class Conv2d(nn.Module):
@@ -100,10 +102,14 @@ class Conv2d(nn.Module):
             self._lowp_version = w._version
         return self._lowp
 
-    def forward(self, x: torch.Tensor, with_stats: bool = False):
+    def forward(self, x: torch.Tensor, with_stats: bool = False, passthrough: bool = False):
         w_lowp = self.lowp_weight(x.dtype) if (B.use_hip(x) and x.dtype != self.weight.dtype) else None
         return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                      self.groups, w_lowp, with_stats)
+                      self.groups, w_lowp, with_stats, passthrough)
+
+    def can_passthrough(self, x: torch.Tensor) -> bool:
+        return (B.use_hip(x) and self.groups == 1 and self.in_channels % 8 == 0 and x.dtype == torch.bfloat16
+                and torch.is_grad_enabled() and x.requires_grad)
 
     def can_fuse_stats(self, x: torch.Tensor) -> bool:
         return (B.use_hip(x) and self.groups == 1 and self.out_channels % 8 == 0
@@ -123,10 +129,25 @@ class Conv2d(nn.Module):
 
 
 def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, passthrough: bool = False):
     """``act(BN(conv(x)) + residual)``.  On the GPU path the batch statistics come out of the conv
-    kernel's epilogue (no separate statistics pass over the activation)."""
+    kernel's epilogue (no separate statistics pass over the activation).
+
+    ``passthrough=True`` returns ``(out, x')`` where ``x'`` is ``x`` routed through the convolution's
+    autograd node: use ``x'`` as the block's identity and the skip-path gradient is added inside the
+    data-gradient kernel (csrc/conv_igemm2.hip store loop) instead of by an add kernel."""
+    pt = passthrough and conv.can_passthrough(x)
     if bn.training and not bn.frozen and conv.can_fuse_stats(x):
-        y, stats = conv(x, with_stats=True)
-        return bn(y, relu=relu, residual=residual, stats=stats)
-    return bn(conv(x), relu=relu, residual=residual)
+        if pt:
+            y, stats, skip = conv(x, with_stats=True, passthrough=True)
+        else:
+            y, stats = conv(x, with_stats=True)
+        out = bn(y, relu=relu, residual=residual, stats=stats)
+    elif pt:
+        y, skip = conv(x, passthrough=True)
+        out = bn(y, relu=relu, residual=residual)
+    else:
+        out = bn(conv(x), relu=relu, residual=residual)
+    if passthrough:
+        return out, (skip if pt else x)
+    return out
