@@ -216,11 +216,51 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
     else:
         dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
                          memory_format=torch.channels_last).zero_()
+    if splits == 0 and _AUTOTUNE and not _WGRAD_GEN1:
+        key = ("wgrad", n, hi, wi, cin, ho, wo, cout, r, s, tuple(stride), tuple(pad), tuple(dil))
+        splits = _TUNED.get(key)
+        if splits is None:
+            splits = _TUNED[key] = _autotune_wgrad(dy, x, dw, (n, hi, wi, cin, ho, wo, cout, r, s), stride, pad, dil)
+            _save_tuned()
     B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
                                  stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, _WGRAD_GEN1,
                                  B.stream_ptr()),
             "conv_wgrad")
     return dw
+
+
+def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil) -> int:
+    """Split-K count of the weight-gradient kernel, measured once per problem.  How well
+    tiles x splits fills the 512 resident block slots (2 per CU) decides the time as much as the
+    atomic-combine traffic does (gpurun_out/s18_wgrad_sweep.log: layer-3 3x3 takes 60 us at 432
+    blocks, 81 us at 576), so the cost model's choice (0) competes with counts that land on
+    0.5 / 0.75 / 1 / 1.5 / 2 / 3 rounds of blocks."""
+    n, hi, wi, cin, ho, wo, cout, r, s = geom
+    lib, stream = _lib(), B.stream_ptr()
+    tiles = ((cout + 127) // 128) * ((r * s * cin + 127) // 128)
+    steps_total = (n * ho * wo + 63) // 64
+    cands = [0]
+    for target in (256, 384, 512, 768, 1024, 1536):
+        c = max(1, min(steps_total, int(round(target / tiles))))
+        if c not in cands:
+            cands.append(c)
+    scratch = torch.zeros_like(dw)
+
+    def run(c):
+        return lib.dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(scratch), n, hi, wi, cin, ho, wo, cout, r, s,
+                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], c, 0, stream)
+
+    timed = []
+    for c in cands:
+        B.check(run(c), "wgrad autotune")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            run(c)
+        e1.record()
+        timed.append((c, e0, e1))
+    torch.cuda.synchronize()
+    return min(timed, key=lambda t: t[1].elapsed_time(t[2]))[0]
 
 
 class _ConvIGemm(torch.autograd.Function):
