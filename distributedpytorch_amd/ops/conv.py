@@ -98,7 +98,11 @@ class Conv2d(nn.Module):
         if (self._lowp is None or self._lowp_version != w._version or self._lowp.dtype != dtype
                 or self._lowp.device != w.device):
             with torch.no_grad():
-                self._lowp = w.detach().to(dtype).contiguous(memory_format=torch.channels_last)
+                if (self._lowp is not None and self._lowp.dtype == dtype and self._lowp.device == w.device
+                        and self._lowp.shape == w.shape):
+                    self._lowp.copy_(w.detach())      # same storage: captured graphs keep a valid pointer
+                else:
+                    self._lowp = w.detach().to(dtype).contiguous(memory_format=torch.channels_last)
             self._lowp_version = w._version
         return self._lowp
 

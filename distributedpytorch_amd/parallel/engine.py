@@ -99,9 +99,18 @@ class TrainEngine:
 
     @torch.no_grad()
     def evaluate(self, loader: Iterable, num_classes: int, ignore_index: int = 255,
-                 max_batches: Optional[int] = None) -> Dict[str, float]:
-        """21-class mIoU from a device confusion matrix, merged across ranks (K12 + C6)."""
+                 max_batches: Optional[int] = None, graph: bool = False) -> Dict[str, float]:
+        """21-class mIoU from a device confusion matrix, merged across ranks (K12 + C6).
+
+        ``graph=True`` (GPU): the forward is replayed from a hipGraph per input shape — the
+        reference's batch-1 evaluation is launch-bound (parallel.graphs)."""
         self.model.eval()
+        fwd = self.model
+        if graph and self.on_gpu:
+            if getattr(self, "_graphed", None) is None:
+                from .graphs import GraphedForward
+                self._graphed = GraphedForward(self.model)
+            fwd = self._graphed
         cm = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=self.device)
         loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         n = 0
@@ -111,7 +120,7 @@ class TrainEngine:
             images, target = batch if isinstance(batch, (tuple, list)) else (batch["image"], batch["label"])
             x = self.prepare_input(images)
             y = target.to(self.device, non_blocking=True)
-            out = self.model(x)
+            out = fwd(x)
             loss_sum += self.criterion(out, y).double()
             logits = out[0] if isinstance(out, (tuple, list)) else out
             confusion_matrix(logits, y, num_classes, ignore_index, out=cm)

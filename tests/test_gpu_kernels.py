@@ -493,3 +493,22 @@ def test_batched_weight_transpose_matches_per_layer():
     y = torch.randint(0, 21, (2, 65, 65), device=DEV)
     eng.train_step(x, y)
     check()
+
+
+def test_graphed_eval_forward_matches_eager():
+    """parallel.graphs.GraphedForward: the hipGraph replay of the batch-1 inference forward equals
+    the eager forward, also after the weights changed in place (graphs hold pointers)."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.parallel import GraphedForward
+    torch.manual_seed(0)
+    model = build_model("deeplabv3plus_resnet18", 21).to(DEV).to(memory_format=torch.channels_last).eval()
+    g = GraphedForward(model)
+    for trial in range(3):
+        x = _nhwc(_bf(torch.randn(1, 3, 129, 129, device=DEV)))
+        with torch.no_grad():
+            ref = model(x).float()
+        got = g(x).float()
+        assert torch.equal(got, ref)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(0.97)
