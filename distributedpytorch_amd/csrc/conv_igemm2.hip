@@ -40,6 +40,16 @@ struct Conv2Args {
     float* stats;           // [stat_reps, 2, Cout] or null (never together with bias)
     const bf16_raw* res;    // [M, ldres] or null: added to the output in the store loop (the skip-path
     int ldres;              //   gradient of a residual block joins the data gradient here, no add kernel)
+    // Fused BatchNorm+ReLU backward prologue (data-gradient launches only).  The tensor this kernel
+    // differentiates, a = relu(BN(bnx) [+ identity]), is the previous layer's activation; instead of
+    // da the store loop writes dm = da·[a > 0] and accumulates Σdm, Σdm·x̂ per channel — the two
+    // reductions BN backward needs — so the separate bn_bwd_reduce pass (dy, x, y re-read) is gone.
+    const bf16_raw* bnx;    // [M, Cout] pre-BN activations (x̂ = (bnx − mean)·rstd) or null
+    const bf16_raw* bna;    // [M, Cout] a itself (mask source) or null: mask = bnx·scale + shift > 0
+    const float* bn_mean; const float* bn_rstd;   // [Cout]
+    const float* bn_w; const float* bn_b;         // [Cout] affine parameters or null (1, 0)
+    float* bnsums;          // [bn_reps, 2, Cout]
+    int bn_reps;
     int stat_reps;
     int M;
     int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
@@ -306,23 +316,107 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         constexpr int RPP = T / TPR;              // rows per pass
         const int cpiece = tid % TPR, rsub = tid / TPR;
         const int gcol = n0 + cpiece * 8;
+        if (p.bnx == nullptr) {
 #pragma unroll 4
-        for (int r0 = 0; r0 < BM; r0 += RPP) {
-            const int row = r0 + rsub;
-            const int m = m0 + row;
-            if (m < p.M && gcol < p.Cout) {
-                const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
-                const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
-                uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                if (p.res) {
-                    float a[8], b[8];
-                    unpack8(o, a);
-                    unpack8(*reinterpret_cast<const uint4*>(p.res + (long)m * p.ldres + gcol), b);
+            for (int r0 = 0; r0 < BM; r0 += RPP) {
+                const int row = r0 + rsub;
+                const int m = m0 + row;
+                if (m < p.M && gcol < p.Cout) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
+                    uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    if (p.res) {
+                        float a[8], b[8];
+                        unpack8(o, a);
+                        unpack8(*reinterpret_cast<const uint4*>(p.res + (long)m * p.ldres + gcol), b);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[j] += b[j];
+                        o = pack8(a);
+                    }
+                    *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = o;
+                }
+            }
+        } else {
+            // ---- fused BN+ReLU backward prologue: dm = (dgrad [+ skip]) · mask, Σdm, Σdm·x̂ ----
+            // restrict-qualified locals + a batch of GRP rows per round: all global loads of a round
+            // are issued before the first is consumed (the store loop is otherwise one exposed memory
+            // round trip per row)
+            const bf16_raw* __restrict__ bnx = p.bnx;
+            const bf16_raw* __restrict__ bna = p.bna;
+            const bf16_raw* __restrict__ resp = p.res;
+            bf16_raw* __restrict__ yout = p.y;
+            const bool col_ok = gcol < p.Cout;
+            float mu[8], is[8], sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mu[j] = col_ok ? p.bn_mean[gcol + j] : 0.f;
+                is[j] = col_ok ? p.bn_rstd[gcol + j] : 0.f;
+                sc[j] = (col_ok && p.bn_w ? p.bn_w[gcol + j] : 1.f) * is[j];
+                sh[j] = fmaf(-mu[j], sc[j], col_ok && p.bn_b ? p.bn_b[gcol + j] : 0.f);
+                s1[j] = 0.f; s2[j] = 0.f;
+            }
+            constexpr int NR = BM / RPP;
+            constexpr int GRP = NR % 4 == 0 ? 4 : (NR % 3 == 0 ? 3 : (NR % 2 == 0 ? 2 : 1));
+            for (int r0 = 0; r0 < BM; r0 += GRP * RPP) {
+                uint4 vx[GRP], va[GRP], vr[GRP];
+                bool ok[GRP];
+#pragma unroll
+                for (int g = 0; g < GRP; ++g) {
+                    const int m = m0 + r0 + g * RPP + rsub;
+                    ok[g] = (m < p.M) && col_ok;
+                    const long off = (long)m * p.Cout + gcol;
+                    vx[g] = ok[g] ? *reinterpret_cast<const uint4*>(bnx + off) : make_uint4(0, 0, 0, 0);
+                    va[g] = (ok[g] && bna) ? *reinterpret_cast<const uint4*>(bna + off) : make_uint4(0, 0, 0, 0);
+                    vr[g] = (ok[g] && resp) ? *reinterpret_cast<const uint4*>(resp + (long)m * p.ldres + gcol)
+                                            : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < GRP; ++g) {
+                    if (!ok[g]) continue;
+                    const int row = r0 + g * RPP + rsub;
+                    const int m = m0 + row;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
+                    float a[8], xv[8], b[8];
+                    unpack8(make_uint4(lo.x, lo.y, hi.x, hi.y), a);
+                    unpack8(vx[g], xv);
+                    unpack8(vr[g], b);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a[j] += b[j];
-                    o = pack8(a);
+                    if (bna) {
+                        float av[8];
+                        unpack8(va[g], av);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[j] = av[j] > 0.f ? a[j] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? a[j] : 0.f;
+                    }
+                    const uint4 o = pack8(a);
+                    unpack8(o, a);        // reduce exactly what BN backward will read back (bf16-rounded)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        s1[j] += a[j];
+                        s2[j] = fmaf(a[j], (xv[j] - mu[j]) * is[j], s2[j]);
+                    }
+                    *reinterpret_cast<uint4*>(yout + (long)m * p.ldy + gcol) = o;
                 }
-                *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = o;
+            }
+            __syncthreads();                              // every thread is done reading the C tile
+            float* part = reinterpret_cast<float*>(smem); // [RPP][2][BN]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                part[(rsub * 2 + 0) * BN + cpiece * 8 + j] = s1[j];
+                part[(rsub * 2 + 1) * BN + cpiece * 8 + j] = s2[j];
+            }
+            __syncthreads();
+            float* dst = p.bnsums + (long)(tile_m % p.bn_reps) * 2 * p.Cout;
+            for (int i = tid; i < 2 * BN; i += T) {
+                const int which = i / BN, c = i - which * BN;
+                float v = 0.f;
+#pragma unroll 4
+                for (int r = 0; r < RPP; ++r) v += part[(r * 2 + which) * BN + c];
+                if (n0 + c < p.Cout) atomicAdd(dst + which * p.Cout + n0 + c, v);
             }
         }
     }
@@ -377,6 +471,15 @@ DP_EXPORT int dp_conv_igemm2(const void* x, const void* w, void* y, const float*
                            pad_w, dil_h, dil_w, ldy, cfg, nullptr, 0, st);
 }
 
+namespace {
+// set by dp_conv_igemm2b for the launch it forwards to dp_conv_igemm2r (host-side, same thread)
+thread_local const void* t_bnx = nullptr;
+thread_local const void* t_bna = nullptr;
+thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
+thread_local float* t_bnsums = nullptr;
+thread_local int t_bn_reps = 0;
+}  // namespace
+
 // + res: optional [N*Ho*Wo, ldres] bf16 tensor added to the output (not part of the fused statistics)
 DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
                               int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
@@ -394,6 +497,10 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     Conv2Args p{};
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.y = (bf16_raw*)y; p.bias = bias; p.stats = stats;
     p.res = (const bf16_raw*)res; p.ldres = ldres;
+    p.bnx = (const bf16_raw*)t_bnx; p.bna = (const bf16_raw*)t_bna; p.bnsums = t_bnsums;
+    p.bn_mean = t_bnp[0]; p.bn_rstd = t_bnp[1]; p.bn_w = t_bnp[2]; p.bn_b = t_bnp[3];
+    p.bn_reps = t_bn_reps < 1 ? 1 : t_bn_reps;
+    if (p.bnx && (stats || bias || ldy != Cout)) return -1;
     p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
     p.M = (int)((long)N * Ho * Wo);
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
@@ -418,4 +525,23 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
         case 10: return launch2<256, 128, 4, 2, 2, 2>(p, unit, st);
         default: return -2;
     }
+}
+
+// Data-gradient launch with the fused BN+ReLU backward prologue (see Conv2Args::bnx).  bnx / bna:
+// [N*Ho*Wo, Cout] bf16 (bna may be null: mask recomputed from bnx), bn_mean / bn_rstd / bn_w / bn_b:
+// fp32 [Cout] (bn_w, bn_b may be null), bnsums: fp32 [bn_reps, 2, Cout], zero-initialised.
+DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
+                              int Cout, int R, int S, int smul, int sdiv, int pad_h, int pad_w, int dil_h,
+                              int dil_w, int cfg, const void* res, const void* bnx, const void* bna,
+                              const float* bn_mean, const float* bn_rstd, const float* bn_w, const float* bn_b,
+                              float* bnsums, int bn_reps, hipStream_t st) {
+    if (!bnx || !bn_mean || !bn_rstd || !bnsums || bn_reps < 1) return -1;
+    if (((uintptr_t)bnx | (uintptr_t)bna) & 15) return -3;
+    t_bnx = bnx; t_bna = bna; t_bnsums = bnsums; t_bn_reps = bn_reps;
+    t_bnp[0] = bn_mean; t_bnp[1] = bn_rstd; t_bnp[2] = bn_w; t_bnp[3] = bn_b;
+    const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
+                                   pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
+    t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0;
+    t_bnp[0] = t_bnp[1] = t_bnp[2] = t_bnp[3] = nullptr;
+    return rc;
 }

@@ -34,6 +34,9 @@ class _Projection(nn.Module):
 
 class BasicBlock(nn.Module):
     expansion = 1
+    # set by ResNet._stage for blocks 1..n-1 of a stage: the block's input is the previous block's
+    # output and nothing else reads it
+    input_exclusive = False
 
     def __init__(self, cin: int, planes: int, stride: int = 1, dilation: int = 1,
                  downsample: Optional[nn.Module] = None):
@@ -47,15 +50,18 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         if self.downsample is None:
             # identity routed through conv1's autograd node: its gradient joins conv1's dgrad kernel
-            out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True)
+            # (and conv1 is then the only consumer of x: BN's backward prologue runs in that kernel too)
+            out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True,
+                                        sole_consumer=self.input_exclusive)
         else:
             identity = self.downsample(x)
             out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
-        return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity)
+        return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity, sole_consumer=True)
 
 
 class Bottleneck(nn.Module):
     expansion = 4
+    input_exclusive = False      # see BasicBlock
 
     def __init__(self, cin: int, planes: int, stride: int = 1, dilation: int = 1,
                  downsample: Optional[nn.Module] = None):
@@ -71,12 +77,14 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         if self.downsample is None:
             # identity routed through conv1's autograd node: its gradient joins conv1's dgrad kernel
-            out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True)
+            # (and conv1 is then the only consumer of x: BN's backward prologue runs in that kernel too)
+            out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True,
+                                        sole_consumer=self.input_exclusive)
         else:
             identity = self.downsample(x)
             out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
-        out = conv_bn_act(self.conv2, self.bn2, out, relu=True)
-        return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity)
+        out = conv_bn_act(self.conv2, self.bn2, out, relu=True, sole_consumer=True)
+        return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity, sole_consumer=True)
 
 
 _CFG = {
@@ -136,6 +144,7 @@ class ResNet(nn.Module):
         self.inplanes = planes * block.expansion
         for i in range(1, depth):
             blocks.append(block(self.inplanes, planes, 1, dilation * g[i]))
+            blocks[-1].input_exclusive = True
         return nn.Sequential(*blocks)
 
     def forward(self, x):

@@ -31,6 +31,7 @@ def _lib():
         lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
+        lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 8 + [I, V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -166,6 +167,50 @@ def tuned_table() -> dict:
     return dict(_TUNED)
 
 
+def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, dil, residual, holder):
+    """Data gradient with the previous layer's BN+ReLU backward prologue fused into the store loop
+    (csrc/conv_igemm2.hip, Conv2Args::bnx): returns ``(dm, sdy, sdyx)`` — the ReLU-masked gradient and
+    the per-channel Σdm, Σdm·x̂ — or ``None`` when the second-generation kernel does not take the shape."""
+    n, cin, hi, wi = dy.shape
+    cout, cin_w, r, s = wt.shape
+    ho, wo = out_hw
+    bx = holder["x"]
+    if (cin != cin_w or cin % 8 or cout % 8 or tuple(bx.shape) != (n, cout, ho, wo) or bx.dtype != torch.bfloat16
+            or not bx.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    ba = holder.get("a")
+    if ba is not None and (ba.shape != bx.shape or not ba.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    if residual is not None and (residual.shape != bx.shape or residual.dtype != torch.bfloat16
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    for nm in ("mean", "invstd", "w", "b"):
+        t = holder.get(nm)
+        if t is not None and (t.dtype != torch.float32 or t.numel() != cout or not t.is_contiguous()):
+            return None
+    key = (n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv, tuple(pad), tuple(dil), False, False)
+    cfg = _FORCED_CFG if _FORCED_CFG is not None else _TUNED.get(key)
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    if cfg is None:
+        args = (B.ptr(dy), B.ptr(wt), B.ptr(y), None, None, 1, n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
+                pad[0], pad[1], dil[0], dil[1], cout)
+        cfg = _TUNED[key] = _autotune(args, None, 1, cout, dy.device) if _AUTOTUNE else 1
+        _save_tuned()
+    if cfg <= 0:
+        return None
+    reps = stat_replicas(n * ho * wo)
+    sums = workspace.zeros(reps * 2 * cout, dy.device).view(reps, 2, cout)
+    st = _lib().dp_conv_igemm2b(B.ptr(dy), B.ptr(wt), B.ptr(y), n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
+                                pad[0], pad[1], dil[0], dil[1], cfg, B.ptr(residual), B.ptr(bx), B.ptr(ba),
+                                B.ptr(holder["mean"]), B.ptr(holder["invstd"]), B.ptr(holder.get("w")),
+                                B.ptr(holder.get("b")), B.ptr(sums), reps, B.stream_ptr())
+    if st == -2:
+        return None
+    B.check(st, "conv_igemm2b")
+    red = sums[0] if reps == 1 else sums.sum(0)
+    return y, red[0], red[1]
+
+
 def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
     """wT[c][R-1-r][S-1-s][k] = w[k][r][s][c]; returns logical [Cin,Cout,R,S] stored channels-last."""
     cout, cin, r, s = w_krsc.shape
@@ -198,6 +243,11 @@ def stat_replicas(m_rows: int) -> int:
     return max(1, min(8, tiles // 64))
 
 
+# DPAMD_BN_PROLOGUE=1: run BN+ReLU backward's mask and reductions inside the consumer's data-gradient
+# store loop (dgrad_bn_fused).  Measured at B32 (profiles/r1_bn_prologue_ab_b32.log): 745.5 img/s
+# with it, 754.2 without — the extra tile reads sit in the MFMA kernel's epilogue where nothing hides
+# them, while bn_bwd_reduce streams at ~5 TB/s — so it is OFF by default and kept as a tested option.
+_BN_PROLOGUE = os.environ.get("DPAMD_BN_PROLOGUE", "0") != "0"
 # DPAMD_WGRAD_GEN=1 selects the first-generation weight-gradient kernel (A/B runs, bisection)
 _WGRAD_GEN1 = 1 if os.environ.get("DPAMD_WGRAD_GEN", "2") == "1" else 0
 
@@ -265,7 +315,8 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil) -> int:
 
 class _ConvIGemm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation, with_stats=False, passthrough=False):
+    def forward(ctx, x, weight, bias, w_lowp, stride, padding, dilation, with_stats=False, passthrough=False,
+                bn_holder=None):
         """``passthrough``: additionally return ``x`` itself as the LAST output.  A residual block
         routes its skip connection through it, so the skip-path gradient arrives in THIS backward
         and is added inside the data-gradient kernel instead of by a separate add kernel."""
@@ -303,6 +354,9 @@ class _ConvIGemm(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.weight_param = weight
         ctx.with_stats, ctx.passthrough = with_stats, passthrough
+        # x = relu(BN(..)) of a layer whose ONLY consumer is this convolution: its backward prologue
+        # runs inside this node's data-gradient kernel (see dgrad_bn_fused)
+        ctx.bn_holder = bn_holder if (bn_holder and cin_p == cin and "x" in bn_holder) else None
         if cout_p != cout:
             y = y[:, :cout]
         outs = [y]
@@ -319,7 +373,7 @@ class _ConvIGemm(torch.autograd.Function):
     def backward(ctx, dy, *rest):
         dskip = rest[-1] if ctx.passthrough else None
         if dy is None:
-            return (dskip,) + (None,) * 8
+            return (dskip,) + (None,) * 9
         x, w_used = ctx.saved_tensors
         stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p = ctx.geom
         if cout_p != cout:
@@ -341,7 +395,15 @@ class _ConvIGemm(torch.autograd.Function):
             pad_t = (dilation[0] * (r - 1) - padding[0], dilation[1] * (s - 1) - padding[1])
             if dskip is not None:
                 dskip = as_nhwc(dskip)
-            dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation, residual=dskip)
+            fused = None
+            if ctx.bn_holder is not None and cout_p == cout:
+                fused = dgrad_bn_fused(dy, wt, (hi, wi), stride[0], pad_t, dilation, dskip, ctx.bn_holder)
+            if fused is not None:
+                dx, sdy, sdyx = fused
+                ctx.bn_holder["sums"] = (sdy, sdyx)
+                ctx.bn_holder["dm_ptr"] = dx.data_ptr()
+            else:
+                dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation, residual=dskip)
             if cin_p != cin:
                 dx = dx[:, :cin]
         elif dskip is not None:
@@ -371,7 +433,7 @@ class _ConvIGemm(torch.autograd.Function):
                     dw = dw[:cout, :cin]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(dim=(0, 2, 3))[:cout]
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class _DepthwiseConv(torch.autograd.Function):
@@ -412,13 +474,16 @@ class _DepthwiseConv(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False, passthrough=False):
+def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False, passthrough=False,
+           sole_consumer=False):
     if x.dtype != torch.bfloat16:
         raise TypeError(f"HIP conv path needs bf16 activations, got {x.dtype}")
     if w_lowp is None:
         w_lowp = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if groups == 1:
-        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats, passthrough)
+        holder = getattr(x, "_dpamd_bn_holder", None) if (sole_consumer and _BN_PROLOGUE) else None
+        return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats, passthrough,
+                                holder)
     if passthrough:
         raise NotImplementedError("passthrough is a dense-convolution feature")
     if with_stats:

@@ -80,7 +80,7 @@ def _group_active(group) -> bool:
 class _BatchNormActTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group,
-                conv_stats=None):
+                conv_stats=None, holder=None):
         C = x.shape[1]
         local_count = x.numel() // C
         hip = B.use_hip(x)
@@ -120,6 +120,10 @@ class _BatchNormActTrain(torch.autograd.Function):
             mask_mode = 0 if not relu else (1 if residual is not None else 2)
             ctx.save_for_backward(x, y if mask_mode == 1 else None, w, b, mean, invstd)
             ctx.mask_mode = mask_mode
+            if holder is not None and relu:
+                # what the consumer convolution's data-gradient kernel needs to run this layer's
+                # ReLU mask and backward reductions in its store loop (csrc/conv_igemm2.hip, bnx)
+                holder.update(x=x, a=y if mask_mode == 1 else None, mean=mean, invstd=invstd, w=w, b=b)
         else:
             mean = s / count
             var = (ss / count - mean * mean).clamp_min_(0.0)
@@ -135,6 +139,7 @@ class _BatchNormActTrain(torch.autograd.Function):
             shift = b - mean * scale
             y = _t_apply(x, scale, shift, residual, relu)
             ctx.save_for_backward(x, y if relu else None, w, b, mean, invstd)
+        ctx.holder = holder if (hip and holder) else None
         ctx.hip, ctx.relu, ctx.count, ctx.sync, ctx.pg = hip, relu, count, sync, pg
         ctx.has_res = residual is not None
         ctx.has_affine = weight is not None
@@ -147,7 +152,18 @@ class _BatchNormActTrain(torch.autograd.Function):
         x, y, w, b, mean, invstd = ctx.saved_tensors
         C = x.shape[1]
         need_dres = ctx.has_res and ctx.needs_input_grad[3]
-        if ctx.hip:
+        mask_mode = ctx.mask_mode if ctx.hip else 0
+        fused_dres = None
+        h = ctx.holder
+        if ctx.hip and h is not None and h.get("dm_ptr") == dy.data_ptr() and h.get("sums") is not None:
+            # the consumer's data-gradient kernel already applied the ReLU mask to dy and left the two
+            # reductions behind: no bn_bwd_reduce pass, no mask source read, the residual gradient IS dy
+            sdy, sdyx = h["sums"]
+            h["sums"] = None
+            mask_mode = 0
+            if need_dres:
+                fused_dres, need_dres = dy, False
+        elif ctx.hip:
             from . import _hip_bn
             sdy, sdyx = _hip_bn.bwd_reduce(dy, x, y, mean, invstd, w, b, ctx.mask_mode)
         else:
@@ -166,22 +182,28 @@ class _BatchNormActTrain(torch.autograd.Function):
                         and ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
             if use_sink:
                 # affine gradients are added into the gradient arena by the same kernel
+                from . import _hip_bn
                 dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                             ctx.mask_mode, need_dres, gw, gb, sdy, sdyx)
+                                             mask_mode, need_dres, gw, gb, sdy, sdyx)
+                if fused_dres is not None:
+                    dres = fused_dres
                 for prm in (wp, bp):
                     notify = getattr(prm, "_dpamd_on_grad", None)
                     if notify is not None:
                         notify(prm)
-                return dx, None, None, dres, None, None, None, None, None, None, None
+                return dx, None, None, dres, None, None, None, None, None, None, None, None
+            from . import _hip_bn
             dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                         ctx.mask_mode, need_dres)
+                                         mask_mode, need_dres)
+            if fused_dres is not None:
+                dres = fused_dres
         else:
             dx, dres = _t_bwd_apply(dy, x, y, mean, invstd, w, g_sdy, g_sdyx, ctx.count, ctx.relu, need_dres)
         # affine grads are *local* sums: DDP's gradient all-reduce averages them like any other param
         # clone: the sums may live in the per-step scratch pool, autograd may keep the tensor as .grad
         dweight = sdyx.to(ctx.wdtype, copy=True) if ctx.has_affine else None
         dbias = sdy.to(ctx.wdtype, copy=True) if ctx.has_affine else None
-        return dx, dweight, dbias, dres, None, None, None, None, None, None, None
+        return dx, dweight, dbias, dres, None, None, None, None, None, None, None, None
 
 
 class _BatchNormActFrozen(torch.autograd.Function):
@@ -228,8 +250,12 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
             y = y + residual
         return F.relu(y) if relu else y
     if training:
-        return _BatchNormActTrain.apply(x, weight, bias, residual, running_mean, running_var,
-                                        momentum, eps, relu, group, conv_stats)
+        holder = {} if (relu and B.use_hip(x)) else None
+        y = _BatchNormActTrain.apply(x, weight, bias, residual, running_mean, running_var,
+                                     momentum, eps, relu, group, conv_stats, holder)
+        if holder:
+            y._dpamd_bn_holder = holder      # read by ops._hip_conv.conv2d(..., sole_consumer=True)
+        return y
     invstd = torch.rsqrt(running_var.float() + eps)
     scale = invstd * (weight.float() if weight is not None else 1.0)
     shift = (bias.float() if bias is not None else 0.0) - running_mean.float() * scale

@@ -37,7 +37,8 @@ def conv_out_size(n: int, k: int, s: int, p: int, d: int) -> int:
 # --------------------------------------------------------------------------------------
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            stride: _IntOr2 = 1, padding: _IntOr2 = 0, dilation: _IntOr2 = 1, groups: int = 1,
-           w_lowp: Optional[torch.Tensor] = None, with_stats: bool = False, passthrough: bool = False):
+           w_lowp: Optional[torch.Tensor] = None, with_stats: bool = False, passthrough: bool = False,
+           sole_consumer: bool = False):
     """2-D convolution.  ``w_lowp`` is an optional up-to-date bf16 KRSC copy of ``weight``.
 
     ``with_stats`` (GPU, dense conv only) additionally returns the per-channel ``[R, 2, Cout]``
@@ -46,7 +47,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if B.use_hip(x):
         from . import _hip_conv
         return _hip_conv.conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats,
-                                passthrough)
+                                passthrough, sole_consumer)
     if with_stats:
         raise ValueError("with_stats is a GPU-kernel feature")
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
@@ -106,10 +107,14 @@ class Conv2d(nn.Module):
             self._lowp_version = w._version
         return self._lowp
 
-    def forward(self, x: torch.Tensor, with_stats: bool = False, passthrough: bool = False):
+    def forward(self, x: torch.Tensor, with_stats: bool = False, passthrough: bool = False,
+                sole_consumer: bool = False):
+        """``sole_consumer``: the caller guarantees that ``x`` (a fused BN+ReLU output) feeds nothing
+        but this convolution (and its ``passthrough``), so the whole gradient of ``x`` leaves this
+        node and BN's backward prologue can run inside the data-gradient kernel."""
         w_lowp = self.lowp_weight(x.dtype) if (B.use_hip(x) and x.dtype != self.weight.dtype) else None
         return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                      self.groups, w_lowp, with_stats, passthrough)
+                      self.groups, w_lowp, with_stats, passthrough, sole_consumer)
 
     def can_passthrough(self, x: torch.Tensor) -> bool:
         return (B.use_hip(x) and self.groups == 1 and self.in_channels % 8 == 0 and x.dtype == torch.bfloat16
@@ -133,7 +138,7 @@ class Conv2d(nn.Module):
 
 
 def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
-                residual: Optional[torch.Tensor] = None, passthrough: bool = False):
+                residual: Optional[torch.Tensor] = None, passthrough: bool = False, sole_consumer: bool = False):
     """``act(BN(conv(x)) + residual)``.  On the GPU path the batch statistics come out of the conv
     kernel's epilogue (no separate statistics pass over the activation).
 
@@ -143,15 +148,15 @@ def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
     pt = passthrough and conv.can_passthrough(x)
     if bn.training and not bn.frozen and conv.can_fuse_stats(x):
         if pt:
-            y, stats, skip = conv(x, with_stats=True, passthrough=True)
+            y, stats, skip = conv(x, with_stats=True, passthrough=True, sole_consumer=sole_consumer)
         else:
-            y, stats = conv(x, with_stats=True)
+            y, stats = conv(x, with_stats=True, sole_consumer=sole_consumer)
         out = bn(y, relu=relu, residual=residual, stats=stats)
     elif pt:
-        y, skip = conv(x, passthrough=True)
+        y, skip = conv(x, passthrough=True, sole_consumer=sole_consumer)
         out = bn(y, relu=relu, residual=residual)
     else:
-        out = bn(conv(x), relu=relu, residual=residual)
+        out = bn(conv(x, sole_consumer=sole_consumer), relu=relu, residual=residual)
     if passthrough:
         return out, (skip if pt else x)
     return out

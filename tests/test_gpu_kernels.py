@@ -512,3 +512,40 @@ def test_graphed_eval_forward_matches_eager():
         with torch.no_grad():
             for p in model.parameters():
                 p.mul_(0.97)
+
+
+@pytest.mark.parametrize("block_name", ["Bottleneck", "BasicBlock"])
+def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name):
+    """csrc/conv_igemm2.hip (Conv2Args::bnx): BN+ReLU backward's mask and reductions computed in the
+    consumer's data-gradient store loop give the same parameter and input gradients as the separate
+    bn_bwd_reduce pass.  One residual stage (projection block + 2 identity blocks) keeps the
+    comparison well conditioned (a whole random-init ResNet at batch 2 is chaotic: two runs of the
+    SAME path differ by O(1) once the autotuner picks different tiles)."""
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.ops import _hip_conv
+    block = getattr(resnet, block_name)
+
+    def grads(flag):
+        old = _hip_conv._BN_PROLOGUE
+        _hip_conv._BN_PROLOGUE = flag
+        try:
+            torch.manual_seed(0)
+            cin, planes = 64, 32
+            cout = planes * block.expansion
+            blocks = [block(cin, planes, 1, 1, resnet._Projection(cin, cout, 1)), block(cout, planes), block(cout, planes)]
+            blocks[1].input_exclusive = blocks[2].input_exclusive = True
+            net = torch.nn.Sequential(*blocks).to(DEV).to(memory_format=torch.channels_last).train()
+            x = _nhwc(_bf(torch.randn(4, cin, 33, 31, device=DEV))).requires_grad_(True)
+            t = _nhwc(_bf(torch.randn(4, cout, 33, 31, device=DEV)))
+            (net(x).float() - t.float()).pow(2).mean().backward()
+            g = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+            g["input"] = x.grad.detach().float().clone()
+            return g
+        finally:
+            _hip_conv._BN_PROLOGUE = old
+    g1, g0, g00 = grads(True), grads(False), grads(False)
+    worst = max(_rel(g1[k], g0[k]) for k in g0)
+    noise = max(_rel(g00[k], g0[k]) for k in g0)     # atomics order -> bf16 rounding flips, amplified by BN
+    assert worst < max(3e-2, 4 * noise), (worst, noise)
+
+
