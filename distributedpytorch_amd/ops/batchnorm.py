@@ -92,7 +92,7 @@ class _BatchNormActTrain(torch.autograd.Function):
             if conv_stats is not None and not sync:
                 replicas, s, ss = conv_stats, None, None      # summed inside the apply kernel
             elif conv_stats is not None:
-                red = conv_stats.sum(0)
+                red = conv_stats[0].clone() if conv_stats.shape[0] == 1 else conv_stats.sum(0)
                 s, ss = red[0], red[1]
             else:
                 s, ss = _hip_bn.stats(x)
@@ -100,17 +100,24 @@ class _BatchNormActTrain(torch.autograd.Function):
             s, ss = _t_stats(x)
         count = float(local_count)
         pg = None if group is True else group
-        if sync:
-            # C4: one fused message [Σx | Σx² | count] per layer (2C+1 floats).
+        if sync and x.is_cuda:
+            # C4 on the GPU: ONE message [Σx | Σx²] per layer and nothing else on the stream — the
+            # [2, C] block the conv epilogue (or the statistics kernel) produced is all-reduced in
+            # place (no cat / slice / copy kernels, no host round trip for the count: the sampler drops
+            # the ragged tail, so every rank contributes the same B·H·W).
+            if s.data_ptr() + 4 * C == ss.data_ptr():
+                packed = torch.as_strided(s, (2, C), (C, 1))
+            else:
+                packed = torch.stack([s, ss])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
+            s, ss = packed[0], packed[1]
+            count = float(local_count * dist.get_world_size(pg))
+        elif sync:
+            # CPU/gloo: one fused message [Σx | Σx² | count] per layer (2C+1 floats), ragged batches allowed
             packed = torch.cat([s, ss, s.new_tensor([count])])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
             s, ss = packed[:C].contiguous(), packed[C:2 * C].contiguous()
-            if x.is_cuda:
-                # no device->host sync on the hot path: the sampler drops the ragged tail, so every
-                # rank contributes the same B·H·W (checked under DPAMD_DEBUG in parallel.debug)
-                count = float(local_count * dist.get_world_size(pg))
-            else:
-                count = float(packed[2 * C].item())
+            count = float(packed[2 * C].item())
         if hip:
             # the apply kernel finalises mean / invstd / running statistics itself (block 0)
             w = weight.detach().float().contiguous() if weight is not None else None
@@ -170,9 +177,13 @@ class _BatchNormActTrain(torch.autograd.Function):
             sdy, sdyx = _t_bwd_reduce(dy, x, y, mean, invstd, ctx.relu)
         g_sdy, g_sdyx = sdy, sdyx
         if ctx.sync:
-            packed = torch.cat([sdy, sdyx])
+            # one message [Σdy' | Σdy'·x̂]; the LOCAL sums stay behind for the affine gradients
+            if sdy.is_cuda and sdy.data_ptr() + 4 * C == sdyx.data_ptr():
+                packed = torch.as_strided(sdy, (2, C), (C, 1)).clone()
+            else:
+                packed = torch.stack([sdy, sdyx])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.pg)
-            g_sdy, g_sdyx = packed[:C].contiguous(), packed[C:].contiguous()
+            g_sdy, g_sdyx = packed[0], packed[1]
         if ctx.hip:
             wp, bp = ctx.params
             gw = getattr(wp, "_dpamd_grad_sink", None) if ctx.has_affine else None
