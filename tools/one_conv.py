@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--pass", dest="which", default="fwd")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--splits", type=int, default=0, help="wgrad split-K count (0 = cost model / autotune)")
     a = ap.parse_args()
     pad = a.dil * (a.k - 1) // 2
     ho = (a.hw + 2 * pad - a.dil * (a.k - 1) - 1) // a.stride + 1
@@ -42,7 +43,8 @@ def main():
         elif a.which == "dgrad":
             _hip_conv.igemm(dy, wt, (a.hw, a.hw), 1, a.stride, (pad_t, pad_t), (a.dil, a.dil), tile=a.tile)
         else:
-            _hip_conv.wgrad(dy, x, (a.cout, a.cin, a.k, a.k), (a.stride, a.stride), (pad, pad), (a.dil, a.dil))
+            _hip_conv.wgrad(dy, x, (a.cout, a.cin, a.k, a.k), (a.stride, a.stride), (pad, pad), (a.dil, a.dil),
+                            splits=a.splits)
     torch.cuda.synchronize()
     print("ok")
 
