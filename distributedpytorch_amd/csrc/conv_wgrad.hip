@@ -279,8 +279,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
     const int cch = flat - tap * p.Cin;
     const int tr = tap / p.S, ts = tap - tr * p.S;
     const int tdy = tr * p.dil_h - p.pad_h, tdx = ts * p.dil_w - p.pad_w;
-    unsigned x_voff[4];                                 // UNIT: fixed offsets
-    int pox[4], poy[4], pnb[4];                         // general: pixel state (pnb = n·Hi)
+    unsigned x_voff[4];                                 // UNIT: fixed offsets; general: byte offset of the
+    int pox[4], poy[4];                                 //   row's input pixel (oy·sh, ox·sw) before the tap
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int px = p_begin + i * 16 + row0;
@@ -290,11 +290,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
             pox[i] = px % p.Wo;
             const int t = px / p.Wo;
             poy[i] = t % p.Ho;
-            pnb[i] = (t / p.Ho) * p.Hi;
+            x_voff[i] = (unsigned)(((((t / p.Ho) * p.Hi + poy[i] * p.stride_h) * p.Wi + pox[i] * p.stride_w) * p.Cin) * 2);
         }
     }
     const unsigned x_step = (unsigned)(TP * p.Cin * 2);
     const int adv_x = TP % p.Wo, adv_y = TP / p.Wo;
+    // general path: the offset moves with the pixel by ADDS only (the PMC capture of the first version
+    // showed 6.4 VALU per MFMA, most of it quarter-rate 32-bit multiplies rebuilding the address)
+    const unsigned adv_bytes = (unsigned)((adv_y * p.stride_h * p.Wi + adv_x * p.stride_w) * p.Cin * 2);
+    const unsigned wrapx_bytes = (unsigned)((p.stride_h * p.Wi - p.Wo * p.stride_w) * p.Cin * 2);
+    const unsigned wrapy_bytes = (unsigned)((p.Hi - p.Ho * p.stride_h) * p.Wi * p.Cin * 2);
+    const int tap_bytes = ((tdy * p.Wi + tdx) * p.Cin + cch) * 2;
 
     // The hardware range check looks at the per-lane offset only, so the running pixel offset is kept
     // in the VGPR offsets (one v_add per load and step) and the SGPR offset stays 0.  An out-of-range
@@ -319,11 +325,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
                 const int iy = poy[i] * p.stride_h + tdy, ix = pox[i] * p.stride_w + tdx;
                 const bool ok = n_ok & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
                 // pixels beyond P have n >= N: their offset lies beyond the descriptor and reads zeros
-                const unsigned off = (unsigned)((((pnb[i] + iy) * p.Wi + ix) * p.Cin + cch) * 2);
-                lds_dma16w(rx, xbase + i * 4096, ok ? off : kOOBw, 0);
-                pox[i] += adv_x; poy[i] += adv_y;
-                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; }
-                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; pnb[i] += p.Hi; }
+                lds_dma16w(rx, xbase + i * 4096, ok ? x_voff[i] + (unsigned)tap_bytes : kOOBw, 0);
+                pox[i] += adv_x; poy[i] += adv_y; x_voff[i] += adv_bytes;
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; x_voff[i] += wrapx_bytes; }
+                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; x_voff[i] += wrapy_bytes; }
             }
         }
     };
