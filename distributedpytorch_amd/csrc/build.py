@@ -71,6 +71,22 @@ def build_all(force: bool = False, verbose: bool = False, save_asm: bool = False
         _run([cxx, *HOST_FLAGS, "-shared", host_src, "-o", host_lib], verbose)
 
 
+def build_host_sanitized(verbose: bool = False) -> str:
+    """host_runtime.cpp + its sanitizer driver as ONE executable under ASan + UBSan (host code only:
+    GPU AddressSanitizer is not available on this platform).  Returns the path of the executable."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    exe = os.path.join(OBJ_DIR, "host_runtime_sanitize")
+    srcs = [os.path.join(HERE, "host_runtime.cpp"), os.path.join(HERE, "host_runtime_sanitize.cpp")]
+    if any(_newer(s, exe) for s in srcs):
+        cxx = shutil.which("g++") or "g++"
+        _run([cxx, "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined",
+              "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", *srcs, "-o", exe], verbose)
+    return exe
+
+
 if __name__ == "__main__":
+    if "--sanitize" in sys.argv:
+        print("built:", build_host_sanitized(verbose=True))
+        sys.exit(0)
     build_all(force="--force" in sys.argv, verbose=True, save_asm="--asm" in sys.argv)
     print("built:", [f for f in os.listdir(HERE) if f.endswith(".so")])
