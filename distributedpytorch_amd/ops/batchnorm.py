@@ -112,6 +112,9 @@ class _BatchNormActTrain(torch.autograd.Function):
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
             s, ss = packed[0], packed[1]
             count = float(local_count * dist.get_world_size(pg))
+            from ..parallel import debug
+            if debug.ENABLED:
+                debug.check_equal_batches(local_count, x.device)
         elif sync:
             # CPU/gloo: one fused message [Σx | Σx² | count] per layer (2C+1 floats), ragged batches allowed
             packed = torch.cat([s, ss, s.new_tensor([count])])

@@ -130,6 +130,7 @@ class DistributedDataParallel(nn.Module):
         if g.is_cuda:
             streams.join(g.device)     # weight gradients are produced on the aux stream (ops.streams)
         _dbg(f"launch bucket {b} numel {g.numel()}")
+        self._order.append(b)
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=not _SYNC)
         if work is not None:
             self._works.append(work)
@@ -142,6 +143,7 @@ class DistributedDataParallel(nn.Module):
         self._ready = [False] * len(self.arena.buckets)
         self._works = []
         self._next = 0
+        self._order: List[int] = []
 
     def finish_gradient_sync(self) -> float:
         """Launch whatever did not fire (unused parameters), wait for every bucket, and return the
@@ -154,6 +156,10 @@ class DistributedDataParallel(nn.Module):
                 w.wait()
         if self.arena.flat_g.is_cuda:
             streams.join(self.arena.flat_g.device)
+        from . import debug
+        if debug.ENABLED and self._sync_enabled and self._comm:
+            debug.check_bucket_order(self._order, debug._comm_device(self.arena.flat_g))
+            debug.check_gradients_equal(self.arena.flat_g)
         self.reset_buckets()
         return 1.0 / self.world_size
 

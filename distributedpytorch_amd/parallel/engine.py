@@ -92,9 +92,14 @@ class TrainEngine:
         if last_micro:
             with self.timer.phase("comm_wait"):
                 scale = self.ddp.finish_gradient_sync()
+            from . import debug
+            if debug.ENABLED:
+                debug.check_streams_joined(self.device)
             with self.timer.phase("optim"):
                 self.optimizer.step(grad_scale=scale, zero_grad=True)
             self.global_step += 1
+            if debug.ENABLED and self.global_step % 10 == 1:
+                debug.check_replicas_equal(self.ddp.arena.flat_p, self.model.buffers())
         return loss.detach()
 
     @torch.no_grad()

@@ -226,6 +226,39 @@ def test_engine_two_ranks_stay_in_sync():
     run_ranks(_engine_steps)
 
 
+def _debug_checks(rank, world, tmp):
+    """parallel.debug (DPAMD_DEBUG): a clean run passes every check; replica drift, rank-dependent
+    bucket order and unequal SyncBN shards raise on EVERY rank."""
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine, debug
+    debug.ENABLED = True
+    model = _fcn(seed=31 + rank, sync_bn=True)
+    eng = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.05, device=torch.device("cpu"), bucket_mb=1)
+    x, y = _make_batch(2, 64, seed=200 + rank)
+    for _ in range(2):
+        eng.train_step(x, y)                                  # all checks run inside and pass
+    dev = torch.device("cpu")
+    debug.check_bucket_order([0, 1, 2], dev)
+    with pytest.raises(RuntimeError, match="rank-dependent order"):
+        debug.check_bucket_order([0, 1, 2] if rank == 0 else [0, 2, 1], dev)
+    with pytest.raises(RuntimeError, match="different B"):
+        debug.check_equal_batches(100 + rank, dev)
+    with torch.no_grad():
+        if rank == 1:
+            eng.ddp.arena.flat_p[5] += 1e-3                   # one replica drifts
+    with pytest.raises(RuntimeError, match="drifted apart"):
+        debug.check_replicas_equal(eng.ddp.arena.flat_p)
+    g = eng.ddp.arena.flat_g
+    with torch.no_grad():
+        g.fill_(float(rank))
+    with pytest.raises(RuntimeError, match="different gradients"):
+        debug.check_gradients_equal(g)
+
+
+def test_debug_mode_consistency_checks():
+    run_ranks(_debug_checks)
+
+
 def _nonfinite_abort(rank, world, tmp):
     from distributedpytorch_amd.parallel import dist_env
     loss = torch.tensor(float("nan") if rank == 1 else 1.0)
