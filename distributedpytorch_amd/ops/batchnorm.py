@@ -69,6 +69,17 @@ def _apply_affine(x, scale, shift, residual, relu):
     return _t_apply(x, scale, shift, residual, relu)
 
 
+def _small_all_reduce(packed: torch.Tensor, pg) -> None:
+    """SUM of a [2, C] fp32 statistics block over the ranks: the one-shot xGMI peer-to-peer kernel
+    (parallel.p2p, DPAMD_SYNCBN_P2P=1, default group, GPU) or the backend's all-reduce."""
+    if packed.is_cuda and pg is None:
+        from ..parallel import p2p
+        if p2p.ENABLED and packed.numel() <= p2p._MAXN and packed.is_contiguous():
+            p2p.default_instance().all_reduce_(packed)
+            return
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
+
+
 def _group_active(group) -> bool:
     return (group is not False and dist.is_available() and dist.is_initialized()
             and dist.get_world_size(group if group is not True else None) > 1)
@@ -109,7 +120,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 packed = torch.as_strided(s, (2, C), (C, 1))
             else:
                 packed = torch.stack([s, ss])
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
+            _small_all_reduce(packed, pg)
             s, ss = packed[0], packed[1]
             count = float(local_count * dist.get_world_size(pg))
             from ..parallel import debug
@@ -185,7 +196,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 packed = torch.as_strided(sdy, (2, C), (C, 1)).clone()
             else:
                 packed = torch.stack([sdy, sdyx])
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.pg)
+            _small_all_reduce(packed, ctx.pg)
             g_sdy, g_sdyx = packed[0], packed[1]
         if ctx.hip:
             wp, bp = ctx.params

@@ -1,0 +1,76 @@
+"""One-shot peer-to-peer all-reduce (csrc/p2p_allreduce.hip, parallel/p2p.py) on the GPU.
+
+The ranks are separate PROCESSES that map each other's receive buffers through HIP IPC; on a 1-GPU box
+they share device 0 (the kernels still exchange tagged granules through each other's buffers and must
+run concurrently), on a multi-GPU node each takes its own device."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, sync_bn_case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank % torch.cuda.device_count())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distributedpytorch_amd.parallel.p2p import OneShotAllReduce
+    ar = OneShotAllReduce(None)
+    try:
+        for it, n in enumerate([1, 7, 513, 2048, 4097, 8192] * 3):
+            base = torch.arange(n, device="cuda", dtype=torch.float32) * 0.25 + it
+            t = base * (rank + 1)
+            ar.all_reduce_(t)
+            assert torch.equal(t, base * sum(r + 1 for r in range(world))), (n, it)
+        g = torch.Generator(device="cuda").manual_seed(5 + rank)
+        t = torch.randn(4096, device="cuda", generator=g)
+        mine = t.clone()
+        ar.all_reduce_(t)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        want = parts[0].clone()
+        for p in parts[1:]:
+            want += p                                  # rank order, as the kernel sums
+        assert torch.equal(t, want)
+        ref = t.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, t), "ranks must hold bit-identical results"
+        if sync_bn_case:
+            # SyncBN through the one-shot kernel == BN over the concatenated batch
+            from distributedpytorch_amd import ops
+            from distributedpytorch_amd.parallel import p2p
+            p2p.ENABLED, p2p._default = True, ar
+            torch.manual_seed(3)
+            full = torch.randn(2 * world, 64, 17, 17, device="cuda").to(torch.bfloat16)
+            bn = ops.BatchNorm2d(64, sync=True).cuda().train()
+            bn_ref = ops.BatchNorm2d(64).cuda().train()
+            x = full[2 * rank:2 * rank + 2].contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            xr = full.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = bn(x, relu=True)
+            yr = bn_ref(xr, relu=True)
+            assert torch.allclose(y.float(), yr[2 * rank:2 * rank + 2].float(), atol=3e-2, rtol=3e-2)
+            y.float().pow(2).sum().backward()
+            yr.float().pow(2).sum().backward()
+            assert torch.allclose(x.grad.float(), xr.grad[2 * rank:2 * rank + 2].float(), atol=5e-2, rtol=5e-2)
+            assert torch.allclose(bn.running_mean, bn_ref.running_mean, atol=1e-3)
+        ar.check()
+    finally:
+        ar.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_one_shot_allreduce_across_processes(world):
+    mp.spawn(_worker, args=(world, _free_port(), world == 2), nprocs=world, join=True)
