@@ -77,6 +77,10 @@ def _small_all_reduce(packed: torch.Tensor, pg) -> None:
         if p2p.ENABLED and packed.numel() <= p2p._MAXN and packed.is_contiguous():
             p2p.default_instance().all_reduce_(packed)
             return
+    if packed.is_cuda:
+        from ..parallel.dist_env import all_reduce_
+        all_reduce_(packed, pg)
+        return
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
 
 

@@ -81,7 +81,8 @@ class DistributedDataParallel(nn.Module):
     # ------------------------------------------------------------------
     def _broadcast_initial_state(self, broadcast_buffers: bool) -> None:
         # C1: one broadcast of the whole parameter arena instead of one per step
-        dist.broadcast(self.arena.flat_p, src=0, group=self.process_group)
+        from .dist_env import broadcast_
+        broadcast_(self.arena.flat_p, 0, self.process_group)
         self.arena.refresh_lowp()
         if broadcast_buffers:
             # BN running statistics / counters: one flat message per dtype, not ~300 tiny ones
@@ -91,7 +92,7 @@ class DistributedDataParallel(nn.Module):
                     by_dtype.setdefault(buf.dtype, []).append(buf)
             for bufs in by_dtype.values():
                 flat = torch.cat([b.detach().reshape(-1) for b in bufs])
-                dist.broadcast(flat, src=0, group=self.process_group)
+                broadcast_(flat, 0, self.process_group)
                 off = 0
                 with torch.no_grad():
                     for b in bufs:
@@ -112,6 +113,15 @@ class DistributedDataParallel(nn.Module):
         def hook(param):
             if not self._sync_enabled:
                 return
+            # Once per parameter and step.  Kernels that add into the arena report through
+            # ``_dpamd_on_grad`` and return None to autograd — and PyTorch (2.10) runs the
+            # post-accumulate hook for such an undefined gradient as well, so the same parameter
+            # arrives here twice.  Counting both emptied the bucket counters early: buckets were
+            # all-reduced before their last gradients existed (found by the 2-rank GPU rehearsal with
+            # DPAMD_DEBUG=1; invisible on one rank, where nothing is launched).
+            if self._fired[si]:
+                return
+            self._fired[si] = 1
             self._pending[bucket] -= 1
             if self._pending[bucket] == 0:
                 self._ready[bucket] = True
@@ -131,7 +141,8 @@ class DistributedDataParallel(nn.Module):
             streams.join(g.device)     # weight gradients are produced on the aux stream (ops.streams)
         _dbg(f"launch bucket {b} numel {g.numel()}")
         self._order.append(b)
-        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=not _SYNC)
+        from .dist_env import all_reduce_
+        work = all_reduce_(g, self.process_group, async_op=not _SYNC)
         if work is not None:
             self._works.append(work)
         self.stats["buckets_launched"] += 1
@@ -144,6 +155,7 @@ class DistributedDataParallel(nn.Module):
         self._works = []
         self._next = 0
         self._order: List[int] = []
+        self._fired = [0] * len(self.arena.slots)
 
     def finish_gradient_sync(self) -> float:
         """Launch whatever did not fire (unused parameters), wait for every bucket, and return the
@@ -159,7 +171,7 @@ class DistributedDataParallel(nn.Module):
         from . import debug
         if debug.ENABLED and self._sync_enabled and self._comm:
             debug.check_bucket_order(self._order, debug._comm_device(self.arena.flat_g))
-            debug.check_gradients_equal(self.arena.flat_g)
+            debug.check_gradients_equal(self.arena.flat_g, self.arena)
         self.reset_buckets()
         return 1.0 / self.world_size
 

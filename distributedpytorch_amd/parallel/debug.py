@@ -54,9 +54,17 @@ def _checksum(t: torch.Tensor) -> float:
     return float((f.sum() + 3.0 * f.abs().sum()).item())
 
 
-def check_gradients_equal(flat_g: torch.Tensor) -> None:
-    if _spread(_checksum(flat_g), _comm_device(flat_g)) != 0.0:
-        raise RuntimeError("DPAMD_DEBUG: ranks hold different gradients after the all-reduce")
+def check_gradients_equal(flat_g: torch.Tensor, arena=None) -> None:
+    dev = _comm_device(flat_g)
+    if _spread(_checksum(flat_g), dev) != 0.0:
+        culprit = ""
+        if arena is not None:       # every rank walks the same slots, so the collectives stay paired
+            names = []
+            for sl in arena.slots:
+                if _spread(_checksum(flat_g[sl.offset:sl.offset + sl.numel]), dev) != 0.0:
+                    names.append(f"{sl.name}(bucket {sl.bucket})")
+            culprit = ": " + ", ".join(names[:12]) + (" ..." if len(names) > 12 else "")
+        raise RuntimeError("DPAMD_DEBUG: ranks hold different gradients after the all-reduce" + culprit)
 
 
 def check_replicas_equal(flat_p: torch.Tensor, buffers: Iterable[torch.Tensor] = ()) -> None:

@@ -98,6 +98,34 @@ def master_first():
             barrier()
 
 
+def _stage_through_host(t: torch.Tensor, group=None) -> bool:
+    """gloo cannot be trusted with GPU tensors here (its worker threads block in stream
+    synchronisation while other threads launch; 2 ranks sharing one MI355X stall): the multi-rank
+    REHEARSAL configuration (gloo backend, GPU tensors) moves the message through the host on the
+    calling thread instead.  RCCL ("nccl") never takes this path."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, group=None, async_op: bool = False):
+    """SUM all-reduce of ``t`` in place; returns a work handle only for ``async_op`` on a backend that
+    runs it on its own stream (RCCL)."""
+    if _stage_through_host(t, group):
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
+    if _stage_through_host(t, group):
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
 def all_reduce_scalar(value: float, op: str = "sum", device: Optional[torch.device] = None) -> float:
     if get_world_size() == 1:
         return float(value)

@@ -99,7 +99,13 @@ class TrainEngine:
                 self.optimizer.step(grad_scale=scale, zero_grad=True)
             self.global_step += 1
             if debug.ENABLED and self.global_step % 10 == 1:
-                debug.check_replicas_equal(self.ddp.arena.flat_p, self.model.buffers())
+                # running statistics are rank-local unless every BatchNorm is synchronised
+                bns = [m for m in self.model.modules() if hasattr(m, "running_mean") and hasattr(m, "sync")]
+                all_sync = bool(bns) and all(m.sync for m in bns)
+                debug.check_replicas_equal(self.ddp.arena.flat_p, self.model.buffers() if all_sync else ())
+            from . import p2p
+            if p2p._default is not None and self.global_step % p2p.CHECK_EVERY == 0:
+                p2p._default.check()      # a peer that never arrived (bounded spin) surfaces here
         return loss.detach()
 
     @torch.no_grad()

@@ -22,7 +22,9 @@ from ..ops import _backend as B
 
 ENABLED = os.environ.get("DPAMD_SYNCBN_P2P", "0") != "0"
 _MAXN = 8192            # floats per message: 2 x 4096 channels
-_TIMEOUT_MS = int(os.environ.get("DPAMD_P2P_TIMEOUT_MS", "5000"))
+# every spin is bounded: ranks may be skewed by seconds while they autotune in the first step
+_TIMEOUT_MS = int(os.environ.get("DPAMD_P2P_TIMEOUT_MS", "30000"))
+CHECK_EVERY = int(os.environ.get("DPAMD_P2P_CHECK_EVERY", "20"))   # steps between host reads of the error word
 _sigs = False
 
 

@@ -74,3 +74,43 @@ def _worker(rank, world, port, sync_bn_case):
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_one_shot_allreduce_across_processes(world):
     mp.spawn(_worker, args=(world, _free_port(), world == 2), nprocs=world, join=True)
+
+
+def _engine_worker(rank, world, port, sync_bn):
+    """Two ranks (processes) train DeepLabv3+ R18 through the full GPU path — arena sinks, aux-stream
+    weight gradients, hook-launched buckets, SyncBN over the one-shot kernel — with every
+    parallel.debug check on: bucket order, identical gradients after the all-reduce, identical
+    replicas.  (Regression: gradient hooks counted twice emptied the bucket counters early.)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", DPAMD_DIST_BACKEND="gloo")
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine, debug, dist_env, init_distributed, p2p
+    debug.ENABLED = True
+    p2p.ENABLED, p2p.CHECK_EVERY = bool(sync_bn), 1
+    info = init_distributed()
+    try:
+        torch.manual_seed(7 + rank)                      # different init per rank: the broadcast must fix it
+        model = build_model("deeplabv3plus_resnet18", 21, sync_bn=sync_bn)
+        eng = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.01, device=info.device, bucket_mb=4)
+        assert len(eng.ddp.arena.buckets) >= 3
+        g = torch.Generator().manual_seed(50 + rank)
+        x = torch.randn(2, 3, 97, 97, generator=g).to(info.device)
+        y = torch.randint(0, 21, (2, 97, 97), generator=g).to(info.device)
+        losses = [float(eng.train_step(x, y)) for _ in range(4)]
+        assert all(l == l for l in losses)
+        assert eng.ddp.stats["buckets_launched"] == 4 * len(eng.ddp.arena.buckets)
+        flat = eng.ddp.arena.flat_p.detach().cpu()
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(flat, other), "replicas diverged"
+    finally:
+        if p2p._default is not None:
+            p2p._default.close()
+            p2p._default = None
+        dist_env.shutdown()
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_two_rank_engine_on_gpu_with_debug_checks(sync_bn):
+    mp.spawn(_engine_worker, args=(2, _free_port(), sync_bn), nprocs=2, join=True)
