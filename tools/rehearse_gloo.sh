@@ -8,8 +8,8 @@ shift
 out=gpurun_out/rehearse_${tag}.log
 ( while true; do sleep 25; echo "hb $(date +%T)"; done ) &
 hb=$!
-env "${envs[@]}" DPAMD_HANG_DUMP_S=80 DPAMD_DIST_BACKEND=gloo timeout -k 5 110 python -m torch.distributed.run --nnodes=1 \
-    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 "$@" > $out 2>&1
+env DPAMD_HANG_DUMP_S=150 DPAMD_DIST_BACKEND=gloo "${envs[@]}" timeout -k 5 170 python -m torch.distributed.run --nnodes=1 \
+    --nproc-per-node ${NPROC:-2} --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus ${NPROC:-2} "$@" > $out 2>&1
 rc=$?
 kill $hb
 echo "== $tag rc=$rc"
