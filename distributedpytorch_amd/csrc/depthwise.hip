@@ -6,6 +6,7 @@
 //   bwd_data   dx[n,iy,ix,c] = Σ_t dy[n,(iy+p-r·d)/s,(ix+p-q·d)/s,c] · w[t][c]   (where divisible)
 //   bwd_weight dw[t][c]      = Σ_{n,oy,ox} dy · x      (column reduction, same mapping as BN stats)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -144,12 +145,180 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_raw* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second generation: strip mapping.  The rocprofv3 trace of Xception-65 (profiles/
+// r1_native_x65_os8_b16.md) shows the kernels above 3-11x off the HBM time of their tensors
+// (bwd_weight 445 us for 197 MB): a grid-stride loop sends consecutive iterations of a thread to pixels
+// a thousand apart, so none of the 9 overlapping taps is ever found in the CU's L1, the 9 weight vectors
+// are re-loaded per pixel, and every element pays three integer divisions.  Here a thread owns ONE
+// channel group (8 channels) and a strip of kStrip CONSECUTIVE pixels: the weights (fwd / bwd_data) or
+// the 72 partial sums (bwd_weight) live in registers for the whole strip, the pixel coordinates advance
+// by increments, and the taps of neighbouring pixels hit in L1.  A block is 32 channel groups x 8
+// strips (a wave-instruction moves 2 x 512 contiguous bytes).
+constexpr int kSlab = 32;      // channel groups per block
+constexpr int kStrips = 8;     // strips per block (kSlab * kStrips = 256 threads)
+
+struct Strip { int cg; long p0, p1; bool active; };
+
+template <int STRIP>
+__device__ __forceinline__ Strip make_strip(int C8, long P) {
+    Strip s;
+    const int cgl = threadIdx.x % kSlab, st = threadIdx.x / kSlab;
+    s.cg = blockIdx.y * kSlab + cgl;
+    s.p0 = ((long)blockIdx.x * kStrips + st) * STRIP;
+    s.p1 = min(P, s.p0 + STRIP);
+    s.active = s.cg < C8 && s.p0 < P;
+    return s;
+}
+
+template <int STRIP>
+__global__ __launch_bounds__(256) void dwconv2_fwd_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w9,
+                                                          bf16_raw* __restrict__ y, Dw p) {
+    const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Ho * p.Wo);
+    if (!s.active) return;
+    float w[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) unpack8(*reinterpret_cast<const uint4*>(w9 + t * p.C + s.cg * 8), w[t]);
+    int ox = (int)(s.p0 % p.Wo);
+    long t2 = s.p0 / p.Wo;
+    int oy = (int)(t2 % p.Ho);
+    int n = (int)(t2 / p.Ho);
+    for (long r = s.p0; r < s.p1; ++r) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const bf16_raw* xn = x + (long)n * p.Hi * p.Wi * p.C + s.cg * 8;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int iy = oy * p.stride - p.pad_h + a * p.dil;
+            if ((unsigned)iy >= (unsigned)p.Hi) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ix = ox * p.stride - p.pad_w + q * p.dil;
+                if ((unsigned)ix >= (unsigned)p.Wi) continue;
+                float xv[8];
+                unpack8(*reinterpret_cast<const uint4*>(xn + ((long)iy * p.Wi + ix) * p.C), xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[a * 3 + q][j], acc[j]);
+            }
+        }
+        *reinterpret_cast<uint4*>(y + r * p.C + s.cg * 8) = pack8(acc);
+        if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++n; } }
+    }
+}
+
+// stride 1 only: dx[iy, ix] = Σ_t dy[iy + pad - a·dil, ix + pad - q·dil] · w[t]
+template <int STRIP>
+__global__ __launch_bounds__(256) void dwconv2_bwd_data_kernel(const bf16_raw* __restrict__ dy,
+                                                               const bf16_raw* __restrict__ w9,
+                                                               bf16_raw* __restrict__ dx, Dw p) {
+    const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Hi * p.Wi);
+    if (!s.active) return;
+    float w[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) unpack8(*reinterpret_cast<const uint4*>(w9 + t * p.C + s.cg * 8), w[t]);
+    int ix = (int)(s.p0 % p.Wi);
+    long t2 = s.p0 / p.Wi;
+    int iy = (int)(t2 % p.Hi);
+    int n = (int)(t2 / p.Hi);
+    for (long r = s.p0; r < s.p1; ++r) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const bf16_raw* dn = dy + (long)n * p.Ho * p.Wo * p.C + s.cg * 8;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int oy = iy + p.pad_h - a * p.dil;
+            if ((unsigned)oy >= (unsigned)p.Ho) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ox = ix + p.pad_w - q * p.dil;
+                if ((unsigned)ox >= (unsigned)p.Wo) continue;
+                float dv[8];
+                unpack8(*reinterpret_cast<const uint4*>(dn + ((long)oy * p.Wo + ox) * p.C), dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(dv[j], w[a * 3 + q][j], acc[j]);
+            }
+        }
+        *reinterpret_cast<uint4*>(dx + r * p.C + s.cg * 8) = pack8(acc);
+        if (++ix == p.Wi) { ix = 0; if (++iy == p.Hi) { iy = 0; ++n; } }
+    }
+}
+
+template <int STRIP>
+__global__ __launch_bounds__(256) void dwconv2_bwd_weight_kernel(const bf16_raw* __restrict__ dy,
+                                                                 const bf16_raw* __restrict__ x,
+                                                                 float* __restrict__ dw9, Dw p) {
+    __shared__ float red[kStrips][kSlab][9];       // one channel of the 8 at a time
+    const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Ho * p.Wo);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    if (s.active) {
+        int ox = (int)(s.p0 % p.Wo);
+        long t2 = s.p0 / p.Wo;
+        int oy = (int)(t2 % p.Ho);
+        int n = (int)(t2 / p.Ho);
+        for (long r = s.p0; r < s.p1; ++r) {
+            float dv[8];
+            unpack8(*reinterpret_cast<const uint4*>(dy + r * p.C + s.cg * 8), dv);
+            const bf16_raw* xn = x + (long)n * p.Hi * p.Wi * p.C + s.cg * 8;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int iy = oy * p.stride - p.pad_h + a * p.dil;
+                if ((unsigned)iy >= (unsigned)p.Hi) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int ix = ox * p.stride - p.pad_w + q * p.dil;
+                    if ((unsigned)ix >= (unsigned)p.Wi) continue;
+                    float xv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(xn + ((long)iy * p.Wi + ix) * p.C), xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[a * 3 + q][j] = fmaf(dv[j], xv[j], acc[a * 3 + q][j]);
+                }
+            }
+            if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++n; } }
+        }
+    }
+    // block combine over the 8 strips, one of the 8 channels per round; then one atomic per (tap, channel)
+    const int cgl = threadIdx.x % kSlab, st = threadIdx.x / kSlab;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[st][cgl][t] = acc[t][j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < kSlab * 9; i += 256) {
+            const int c = i / 9, t = i - c * 9;
+            const int cg = blockIdx.y * kSlab + c;
+            if (cg >= (p.C >> 3)) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < kStrips; ++k) v += red[k][c][t];
+            atomicAdd(dw9 + t * p.C + cg * 8 + j, v);
+        }
+    }
+}
+
 }  // namespace
 
 DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
                             int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
+    // strip mapping measured SLOWER here than the flat mapping (176 vs 111 us on the 728-channel 65x65
+    // layers: a wave's loads split into two 512-B runs and a thread walks 8 pixels serially); it pays
+    // only in bwd_weight, where it removes the per-pixel register spill of partial sums.  Opt-in: =2.
+    static const bool gen2 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 2;
+    const long P = (long)N * Ho * Wo;
+    const long nb = (P + kStrips * 8 - 1) / (kStrips * 8);
+    if (gen2 && nb <= 0x7fffffffL) {
+        hipLaunchKernelGGL(dwconv2_fwd_kernel<8>, dim3((unsigned)nb, (unsigned)((C / 8 + kSlab - 1) / kSlab)), dim3(256),
+                           0, st, (const bf16_raw*)x, (const bf16_raw*)w9, (bf16_raw*)y, p);
+        return DP_LAUNCH_STATUS();
+    }
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_1d((long)N * Ho * Wo * (C / 8), 256)), dim3(256), 0, st,
                        (const bf16_raw*)x, (const bf16_raw*)w9, (bf16_raw*)y, p);
     return DP_LAUNCH_STATUS();
@@ -159,6 +328,14 @@ DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N
                                  int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
+    static const bool gen2 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 2;   // see dp_dwconv_fwd
+    const long Pin = (long)N * Hi * Wi;
+    const long nbs = (Pin + kStrips * 8 - 1) / (kStrips * 8);
+    if (gen2 && stride == 1 && nbs <= 0x7fffffffL) {
+        hipLaunchKernelGGL(dwconv2_bwd_data_kernel<8>, dim3((unsigned)nbs, (unsigned)((C / 8 + kSlab - 1) / kSlab)),
+                           dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)w9, (bf16_raw*)dx, p);
+        return DP_LAUNCH_STATUS();
+    }
     hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_1d((long)N * Hi * Wi * (C / 8), 256)), dim3(256), 0, st,
                        (const bf16_raw*)dy, (const bf16_raw*)w9, (bf16_raw*)dx, p);
     return DP_LAUNCH_STATUS();
@@ -169,6 +346,16 @@ DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
     const int C8 = C / 8;
+    static const bool gen1 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 1;
+    {
+        const long P = (long)N * Ho * Wo;
+        const long nbw = (P + kStrips * 32 - 1) / (kStrips * 32);
+        if (!gen1 && nbw <= 0x7fffffffL) {
+            hipLaunchKernelGGL(dwconv2_bwd_weight_kernel<32>, dim3((unsigned)nbw, (unsigned)((C8 + kSlab - 1) / kSlab)),
+                               dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p);
+            return DP_LAUNCH_STATUS();
+        }
+    }
     const int cgs = C8 < 256 ? C8 : 256;
     const int rpp = 256 / cgs;
     long nb = ((long)N * Ho * Wo + (long)rpp * 8 - 1) / ((long)rpp * 8);

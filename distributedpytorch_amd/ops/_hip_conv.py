@@ -167,7 +167,7 @@ def tuned_table() -> dict:
     return dict(_TUNED)
 
 
-def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, dil, residual, holder):
+def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, dil, residual, holder, a=None):
     """Data gradient with the previous layer's BN+ReLU backward prologue fused into the store loop
     (csrc/conv_igemm2.hip, Conv2Args::bnx): returns ``(dm, sdy, sdyx)`` — the ReLU-masked gradient and
     the per-channel Σdm, Σdm·x̂ — or ``None`` when the second-generation kernel does not take the shape."""
@@ -178,7 +178,9 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
     if (cin != cin_w or cin % 8 or cout % 8 or tuple(bx.shape) != (n, cout, ho, wo) or bx.dtype != torch.bfloat16
             or not bx.is_contiguous(memory_format=torch.channels_last)):
         return None
-    ba = holder.get("a")
+    ba = a if holder.get("mask_from_a") else None      # the activation itself = this convolution's input
+    if holder.get("mask_from_a") and ba is None:
+        return None
     if ba is not None and (ba.shape != bx.shape or not ba.is_contiguous(memory_format=torch.channels_last)):
         return None
     if residual is not None and (residual.shape != bx.shape or residual.dtype != torch.bfloat16
@@ -397,7 +399,7 @@ class _ConvIGemm(torch.autograd.Function):
                 dskip = as_nhwc(dskip)
             fused = None
             if ctx.bn_holder is not None and cout_p == cout:
-                fused = dgrad_bn_fused(dy, wt, (hi, wi), stride[0], pad_t, dilation, dskip, ctx.bn_holder)
+                fused = dgrad_bn_fused(dy, wt, (hi, wi), stride[0], pad_t, dilation, dskip, ctx.bn_holder, x)
             if fused is not None:
                 dx, sdy, sdyx = fused
                 ctx.bn_holder["sums"] = (sdy, sdyx)

@@ -60,6 +60,7 @@ class TrainEngine:
         self._micro = 0
         self.timer = PhaseTimer(self.on_gpu, markers)
         self.global_step = 0
+        self._step_events: list = []      # bounds how far the host may run ahead of the GPU
 
     # ------------------------------------------------------------------
     def prepare_input(self, images: torch.Tensor) -> torch.Tensor:
@@ -76,6 +77,13 @@ class TrainEngine:
         # TODO `train_pascal.py:5`: "label non_blocking = True"
         y = target.to(self.device, non_blocking=True)
         last_micro = (self._micro + 1) % self.accum_steps == 0
+        if self.on_gpu:
+            # The loss is never read on the host, so nothing stops Python from queueing steps faster than
+            # the GPU retires them; tensors the aux stream still holds (record_stream) cannot be
+            # recycled meanwhile and the caching allocator grows without bound (B128: 280 GiB, OOM).
+            # Wait for the step before the previous one: two steps in flight keep the queues full.
+            if len(self._step_events) >= 2:
+                self._step_events.pop(0).synchronize()
         workspace.begin_step(self.device)   # one memset re-arms every reduction accumulator of the step
         with self.timer.phase("fwd"):
             out = self.ddp(x)
@@ -98,6 +106,10 @@ class TrainEngine:
             with self.timer.phase("optim"):
                 self.optimizer.step(grad_scale=scale, zero_grad=True)
             self.global_step += 1
+            if self.on_gpu:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._step_events.append(ev)
             if debug.ENABLED and self.global_step % 10 == 1:
                 # running statistics are rank-local unless every BatchNorm is synchronised
                 bns = [m for m in self.model.modules() if hasattr(m, "running_mean") and hasattr(m, "sync")]
