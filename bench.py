@@ -33,8 +33,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DPAMD_BENCH_BATCH", "64")),
-                    help="per-GPU batch (64 x 513² holds 28 GiB of the 288 GB HBM3E)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DPAMD_BENCH_BATCH", "128")),
+                    help="per-GPU batch (128 x 513² holds 55 GiB of the 288 GB HBM3E)")
     ap.add_argument("--crop", type=int, default=513)
     ap.add_argument("--model", default="deeplabv3plus_resnet101")
     ap.add_argument("--output-stride", type=int, default=None)
