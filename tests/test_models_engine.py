@@ -278,3 +278,60 @@ def test_gpu_augment_reference_path_cpu():
     mats = ops.make_affine_params(B, (S, S), (S, S), scales=(0.5, 0.5), flip_p=0.0, rng=np.random.default_rng(0))
     _, y2 = ops.affine_augment(img, lab, torch.from_numpy(mats), (S, S), out_dtype=torch.float32)
     assert (y2 == 255).any()       # zoom-out exposes the border → ignore label
+
+
+def test_loss_upsamples_lowres_logits_like_interpolate():
+    """ops.softmax_cross_entropy with a label map larger than the logits = CE of the bilinearly
+    (align_corners) upsampled logits — the contract of the fused GPU kernel, on the CPU path."""
+    import torch.nn.functional as F
+    from distributedpytorch_amd import ops
+    torch.manual_seed(0)
+    logits = torch.randn(2, 5, 9, 7, requires_grad=True)
+    target = torch.randint(0, 5, (2, 33, 25))
+    target[:, :3] = 255
+    got = ops.softmax_cross_entropy(logits, target, 255)
+    up = F.interpolate(logits, size=(33, 25), mode="bilinear", align_corners=True)
+    ref = F.cross_entropy(up, target, ignore_index=255)
+    assert torch.allclose(got, ref, atol=1e-6)
+    g1, = torch.autograd.grad(got, logits)
+    g2, = torch.autograd.grad(ref, logits)
+    assert torch.allclose(g1, g2, atol=1e-6)
+
+
+def test_engine_defers_final_upsample_only_in_training():
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(0)
+    model = build_model("deeplabv3plus_resnet18", 21)
+    assert model.defer_upsample is False
+    eng = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.01, device=torch.device("cpu"))
+    assert model.defer_upsample is True
+    x = torch.randn(2, 3, 65, 65)
+    y = torch.randint(0, 21, (2, 65, 65))
+    model.train()
+    assert model(x).shape[-2:] == (17, 17)            # stride-4 logits, upsampled inside the loss
+    model.eval()
+    with torch.no_grad():
+        assert model(x).shape[-2:] == (65, 65)        # evaluation sees full resolution
+    l0 = float(eng.train_step(x, y))
+    for _ in range(5):
+        l1 = float(eng.train_step(x, y))
+    assert l1 < l0
+
+
+def test_conv_passthrough_routes_skip_gradient_cpu():
+    """conv_bn_act(passthrough=True) returns the input as the block's identity; gradients equal the
+    plain formulation (on the GPU the skip gradient is added inside the data-gradient kernel)."""
+    from distributedpytorch_amd.ops import BatchNorm2d, Conv2d, conv_bn_act
+    torch.manual_seed(1)
+    conv, bn = Conv2d(8, 8, 3, padding=1, bias=False), BatchNorm2d(8)
+    x1 = torch.randn(2, 8, 9, 9, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    out, ident = conv_bn_act(conv, bn, x1, relu=True, passthrough=True)
+    (out + ident).pow(2).sum().backward()
+    gw = conv.weight.grad.clone()
+    conv.weight.grad = None
+    (conv_bn_act(conv, bn, x2, relu=True) + x2).pow(2).sum().backward()
+    assert torch.allclose(x1.grad, x2.grad, atol=1e-5)
+    assert torch.allclose(gw, conv.weight.grad, atol=1e-5)
