@@ -28,8 +28,8 @@ class _ASPPBranch(nn.Module):
         self.atrous_conv = Conv2d(cin, cout, k, padding=p, dilation=dilation, bias=False)
         self.bn = BatchNorm2d(cout)
 
-    def forward(self, x):
-        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True)
+    def forward(self, x, passthrough: bool = False):
+        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True, passthrough=passthrough)
 
 
 class _ImagePool(nn.Module):
@@ -61,9 +61,16 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         h, w = x.shape[2:]
+        # five consumers of x: thread it through the four convolutions' autograd nodes so their
+        # data-gradient kernels accumulate dL/dx in the store loop (no 4 add kernels over the
+        # 2048-channel map; see models.resnet._FanOutMixin)
+        b1, x = self.aspp1(x, passthrough=True)
+        b2, x = self.aspp2(x, passthrough=True)
+        b3, x = self.aspp3(x, passthrough=True)
+        b4, x = self.aspp4(x, passthrough=True)
         pooled = self.global_avg_pool(x)
         pooled = pooled.expand(-1, -1, h, w)  # align_corners bilinear of a 1×1 map = broadcast
-        y = torch.cat([self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), pooled], dim=1)
+        y = torch.cat([b1, b2, b3, b4, pooled], dim=1)
         y = conv_bn_act(self.conv1, self.bn1, y, relu=True)
         return F.dropout(y, self.p_drop, self.training)
 

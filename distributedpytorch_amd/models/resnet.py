@@ -28,11 +28,37 @@ class _Projection(nn.Module):
         self.add_module("0", Conv2d(cin, cout, 1, stride=stride, bias=False))
         self.add_module("1", BatchNorm2d(cout))
 
-    def forward(self, x):
-        return conv_bn_act(getattr(self, "0"), getattr(self, "1"), x)
+    def forward(self, x, passthrough: bool = False):
+        return conv_bn_act(getattr(self, "0"), getattr(self, "1"), x, passthrough=passthrough)
 
 
-class BasicBlock(nn.Module):
+class _FanOutMixin:
+    """First block of a stage: ``x`` feeds conv1 AND the projection shortcut (and, for the stride-4
+    map, the decoder).  Autograd would sum those gradients with one add kernel per extra consumer —
+    a full read-read-write of the largest activations.  Instead ``x`` is threaded through the
+    consumers' autograd nodes (``passthrough``): each data-gradient kernel adds the gradient that
+    arrived from the consumers after it in its store loop, so the sum costs no launch at all."""
+
+    # set by ResNet for the block whose input another module consumes too: forward leaves the
+    # threaded alias of its input in ``input_alias`` for that consumer to pick up
+    export_input = False
+    input_alias: Optional[torch.Tensor] = None
+
+    def _projected(self, x):
+        out, xp = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True)
+        if self.export_input:
+            identity, xp = self.downsample(xp, passthrough=True)
+            self.input_alias = xp
+        else:
+            identity = self.downsample(xp)
+        return out, identity
+
+    def take_input_alias(self, default: torch.Tensor) -> torch.Tensor:
+        alias, self.input_alias = self.input_alias, None
+        return default if alias is None else alias
+
+
+class BasicBlock(_FanOutMixin, nn.Module):
     expansion = 1
     # set by ResNet._stage for blocks 1..n-1 of a stage: the block's input is the previous block's
     # output and nothing else reads it
@@ -54,12 +80,11 @@ class BasicBlock(nn.Module):
             out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True,
                                         sole_consumer=self.input_exclusive)
         else:
-            identity = self.downsample(x)
-            out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            out, identity = self._projected(x)
         return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity, sole_consumer=True)
 
 
-class Bottleneck(nn.Module):
+class Bottleneck(_FanOutMixin, nn.Module):
     expansion = 4
     input_exclusive = False      # see BasicBlock
 
@@ -81,8 +106,7 @@ class Bottleneck(nn.Module):
             out, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True,
                                         sole_consumer=self.input_exclusive)
         else:
-            identity = self.downsample(x)
-            out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            out, identity = self._projected(x)
         out = conv_bn_act(self.conv2, self.bn2, out, relu=True, sole_consumer=True)
         return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity, sole_consumer=True)
 
@@ -122,6 +146,7 @@ class ResNet(nn.Module):
         self.maxpool = MaxPool3x3s2()
         self.layer1 = self._stage(block, 64, depths[0], strides[0], dilations[0])
         self.layer2 = self._stage(block, 128, depths[1], strides[1], dilations[1])
+        self.layer2[0].export_input = self.layer2[0].downsample is not None
         self.layer3 = self._stage(block, 256, depths[2], strides[2], dilations[2])
         grid = None
         if multi_grid is not None and block is Bottleneck and len(multi_grid) == depths[3]:
@@ -152,6 +177,8 @@ class ResNet(nn.Module):
         x = self.maxpool(x)
         c2 = self.layer1(x)
         x = self.layer2(c2)
+        # the decoder reads the stride-4 map too: hand it the alias threaded through layer2's first block
+        c2 = self.layer2[0].take_input_alias(c2)
         x = self.layer3(x)
         c5 = self.layer4(x)
         return c5, c2

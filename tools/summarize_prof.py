@@ -11,9 +11,10 @@ FAMILIES = [
     ("conv fwd (MIOpen igemm)", r"igemm_fwd"),
     ("conv dgrad (MIOpen/CK)", r"igemm_bwd|conv_bwd_data"),
     ("conv wgrad (MIOpen/CK)", r"igemm_wrw|conv_bwd_weight"),
-    ("dpamd conv igemm", r"dp_conv|igemm_kernel|conv_igemm"),
+    ("dpamd conv wgrad", r"conv_wgrad"),
+    ("dpamd conv fwd/dgrad igemm", r"dp_conv|igemm_kernel|conv_igemm"),
     ("dpamd batchnorm", r"bn_stats_kernel|bn_apply_kernel|bn_bwd"),
-    ("dpamd misc", r"dp_|softmax_ce|bilinear_|maxpool|avgpool|sgd_flat|affine_aug|confusion|dwconv"),
+    ("dpamd misc", r"dp_|softmax_ce|upsample_ce|bilinear_|maxpool|avgpool|sgd_flat|affine_aug|confusion|dwconv|weight_transpose|pad_channels|p2p_"),
     ("MIOpen batchnorm", r"MIOpenBatchNorm"),
     ("upsample (ATen)", r"upsample_bilinear"),
     ("softmax/nll (ATen)", r"SoftMax|nll_loss"),
