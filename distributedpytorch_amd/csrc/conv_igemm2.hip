@@ -53,6 +53,9 @@ struct Conv2Args {
     int stat_reps;
     int M;
     int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
+    int ldx;                // elements between neighbouring input pixels: Cin, or less for OVERLAPPING
+                            //   windows (a pixel's "channels" run on into its right-hand neighbours: the
+                            //   small-Cin stem reads R row segments of S·4 elements instead of R·S taps)
     int smul, sdl, pad_h, pad_w, dil_h, dil_w;   // sdl = log2(sdiv)
     int ldy;
     int csteps, ksteps, ctail;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         for (int i = 0; i < AR; ++i) {
             const int by = oy * p.smul - p.pad_h, bx = ox * p.smul - p.pad_w;
             const int fby = by >> p.sdl, fbx = bx >> p.sdl;          // floor division (arithmetic shift)
-            const unsigned base = (unsigned)((((n * p.Hi + fby) * p.Wi + fbx) * p.Cin + lc * 8) * 2);
+            const unsigned base = (unsigned)((((n * p.Hi + fby) * p.Wi + fbx) * p.ldx + lc * 8) * 2);
             const bool row_ok = m < p.M;
             if (UNIT) {
                 a_voff[i] = row_ok ? base : kOOB;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             }
         } else {
             const int cdy = (kr * p.dil_h + sdr) >> p.sdl, cdx = (ks * p.dil_w + sdr) >> p.sdl;   // ceil(tap / sdiv)
-            const unsigned a_soff = (unsigned)(((cdy * p.Wi + cdx) * p.Cin + kc * BK) * 2);
+            const unsigned a_soff = (unsigned)(((cdy * p.Wi + cdx) * p.ldx + kc * BK) * 2);
             const unsigned tapbit = 1u << (kr * p.S + ks);
             const bool cv = !p.ctail || (lc * 8 < p.Cin - kc * BK);
 #pragma unroll
@@ -478,6 +481,7 @@ thread_local const void* t_bna = nullptr;
 thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
+thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
 }  // namespace
 
 // + res: optional [N*Ho*Wo, ldres] bf16 tensor added to the output (not part of the fused statistics)
@@ -490,7 +494,10 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     if (ldy < Cout || R <= 0 || S <= 0 || smul < 1 || (sdiv != 1 && sdiv != 2 && sdiv != 4)) return -1;
     if (R * S > 32 || (bias && stats) || Cout % 8 != 0 || ldy % 8 != 0) return -2;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return -3;
-    const long x_bytes = (long)N * Hi * Wi * Cin * 2, w_bytes = (long)Cout * R * S * Cin * 2;
+    const int ldx = t_ldx > 0 ? t_ldx : Cin;
+    if (ldx > Cin || (ldx % 8 != 0 && ldx != 4)) return -1;
+    if (ldx != Cin && (S != 1 || res || t_bnx || sdiv != 1)) return -1;   // windows overlap along W only
+    const long x_bytes = (long)N * Hi * Wi * ldx * 2, w_bytes = (long)Cout * R * S * Cin * 2;
     // 32-bit byte offsets below the out-of-range marker, with room for the largest tap offset
     if (x_bytes >= (1L << 31) - (1L << 24) || w_bytes >= (1L << 31) - (1L << 24) || (long)N * Ho * Wo >= (1L << 31) - 512)
         return -4;
@@ -504,6 +511,7 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
     p.M = (int)((long)N * Ho * Wo);
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
+    p.ldx = ldx;
     p.smul = smul; p.sdl = sdiv == 1 ? 0 : (sdiv == 2 ? 1 : 2);
     p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
     p.ldy = ldy;
@@ -511,7 +519,7 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.ksteps = R * S * p.csteps;
     p.ctail = (Cin % BK) != 0;
     p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
-    const bool unit = (R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && sdiv == 1);
+    const bool unit = (R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && sdiv == 1 && ldx == Cin);
     switch (cfg) {
         case 1: return launch2<128, 128, 2, 2, 2, 2>(p, unit, st);
         case 2: return launch2<128, 128, 2, 2, 4, 1>(p, unit, st);
@@ -543,5 +551,25 @@ DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int 
                                    pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
     t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0;
     t_bnp[0] = t_bnp[1] = t_bnp[2] = t_bnp[3] = nullptr;
+    return rc;
+}
+
+// Forward convolution over OVERLAPPING pixel windows (the small-Cin network stem).  x: [N, Hi, Wi, ldx]
+// with ldx = 4 (RGB / RGB+guidance padded to 4 channels, stored with the left padding physically
+// present); a "pixel" of this launch is the Cin = 32-element window starting at a real pixel, i.e. a
+// filter-row segment of 8 pixels, so a 7x7 filter is R = 7 taps of 32 "channels" (weights [Cout][R][1][32],
+// zero where the window runs past the filter) instead of 49 taps of 8 zero-padded channels.  The last
+// window of a row reads up to Cin - ldx elements past its pixel: the caller sizes Wi for it
+// ((Wo-1)*smul + Cin/ldx <= Wi), so every read stays inside its own row.
+DP_EXPORT int dp_conv_igemm2w(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
+                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
+                              int sdiv, int pad_h, int pad_w, int dil_h, int dil_w, int ldy, int cfg, int ldx,
+                              hipStream_t st) {
+    if (ldx <= 0 || S != 1 || pad_w != 0 || dil_w != 1 || Cin % ldx != 0) return -1;
+    if ((long)(Wo - 1) * smul + Cin / ldx > Wi || (Wi * ldx) % 8 != 0) return -1;   // last window ends inside its row
+    t_ldx = ldx;
+    const int rc = dp_conv_igemm2r(x, w, y, bias, stats, stat_reps, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
+                                   pad_h, pad_w, dil_h, dil_w, ldy, cfg, nullptr, 0, st);
+    t_ldx = 0;
     return rc;
 }

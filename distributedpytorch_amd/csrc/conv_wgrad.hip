@@ -223,6 +223,7 @@ struct Wgrad2Args {
     int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
     int NF, tiles_k, tiles_n, splits, px_per_split;
     unsigned x_bytes;
+    int ldx;        // elements between neighbouring input pixels (Cin, or 4 for the overlapping stem windows)
 };
 
 __device__ __forceinline__ void lds_dma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff,
@@ -290,17 +291,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
             pox[i] = px % p.Wo;
             const int t = px / p.Wo;
             poy[i] = t % p.Ho;
-            x_voff[i] = (unsigned)(((((t / p.Ho) * p.Hi + poy[i] * p.stride_h) * p.Wi + pox[i] * p.stride_w) * p.Cin) * 2);
+            x_voff[i] = (unsigned)(((((t / p.Ho) * p.Hi + poy[i] * p.stride_h) * p.Wi + pox[i] * p.stride_w) * p.ldx) * 2);
         }
     }
     const unsigned x_step = (unsigned)(TP * p.Cin * 2);
     const int adv_x = TP % p.Wo, adv_y = TP / p.Wo;
     // general path: the offset moves with the pixel by ADDS only (the PMC capture of the first version
     // showed 6.4 VALU per MFMA, most of it quarter-rate 32-bit multiplies rebuilding the address)
-    const unsigned adv_bytes = (unsigned)((adv_y * p.stride_h * p.Wi + adv_x * p.stride_w) * p.Cin * 2);
-    const unsigned wrapx_bytes = (unsigned)((p.stride_h * p.Wi - p.Wo * p.stride_w) * p.Cin * 2);
-    const unsigned wrapy_bytes = (unsigned)((p.Hi - p.Ho * p.stride_h) * p.Wi * p.Cin * 2);
-    const int tap_bytes = ((tdy * p.Wi + tdx) * p.Cin + cch) * 2;
+    const unsigned adv_bytes = (unsigned)((adv_y * p.stride_h * p.Wi + adv_x * p.stride_w) * p.ldx * 2);
+    const unsigned wrapx_bytes = (unsigned)((p.stride_h * p.Wi - p.Wo * p.stride_w) * p.ldx * 2);
+    const unsigned wrapy_bytes = (unsigned)((p.Hi - p.Ho * p.stride_h) * p.Wi * p.ldx * 2);
+    const int tap_bytes = ((tdy * p.Wi + tdx) * p.ldx + cch) * 2;
 
     // The hardware range check looks at the per-lane offset only, so the running pixel offset is kept
     // in the VGPR offsets (one v_add per load and step) and the SGPR offset stays 0.  An out-of-range
@@ -451,13 +452,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
 }  // namespace
 
 // splits: 0 = auto.  dw must be zero-initialised (or hold a gradient to accumulate into).
+namespace {
+thread_local int t_wg_ldx = 0;     // set by dp_conv_wgrad_win
+}
+
 DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
                             int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                             int dil_w, int splits, int reserved, hipStream_t st) {
+    const int ldx = t_wg_ldx > 0 ? t_wg_ldx : Cin;
     if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0 || N <= 0 || Ho <= 0 || Wo <= 0) return -1;
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) & 15) return -3;
     const long P = (long)N * Ho * Wo;
-    if (P >= (1L << 31) / (Cout > Cin ? Cout : Cin) || (long)N * Hi * Wi * Cin >= (1L << 31)) return -4;
+    if (P >= (1L << 31) / (Cout > Cin ? Cout : Cin) || (long)N * Hi * Wi * ldx >= (1L << 31)) return -4;
     WgradArgs p{};
     p.dy = (const bf16_raw*)dy; p.x = (const bf16_raw*)x; p.dw = (float*)dw;
     p.P = (int)P; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
@@ -494,7 +500,9 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     p.splits = (int)((P + p.px_per_split - 1) / p.px_per_split);
     const long nwg = (long)tiles * p.splits;
     if (nwg > 0x7fffffffL) return -4;
-    const long x_bytes = (long)N * Hi * Wi * Cin * 2;
+    const long x_bytes = (long)N * Hi * Wi * ldx * 2;
+    if (ldx != Cin && (reserved == 1 || x_bytes >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24)))
+        return -2;                                   // windows are a second-generation feature
     if (reserved == 1 || x_bytes >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24)) {
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, p);
         return DP_LAUNCH_STATUS();
@@ -503,9 +511,22 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     q.dy = p.dy; q.x = p.x; q.dw = p.dw; q.P = p.P; q.Hi = Hi; q.Wi = Wi; q.Cin = Cin; q.Ho = Ho; q.Wo = Wo;
     q.Cout = Cout; q.R = R; q.S = S; q.stride_h = stride_h; q.stride_w = stride_w; q.pad_h = pad_h; q.pad_w = pad_w;
     q.dil_h = dil_h; q.dil_w = dil_w; q.NF = p.NF; q.tiles_k = p.tiles_k; q.tiles_n = p.tiles_n; q.splits = p.splits;
-    q.px_per_split = p.px_per_split; q.x_bytes = (unsigned)x_bytes;
-    const bool unit = R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1;
+    q.px_per_split = p.px_per_split; q.x_bytes = (unsigned)x_bytes; q.ldx = ldx;
+    const bool unit = R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1 && ldx == Cin;
     if (unit) hipLaunchKernelGGL(conv_wgrad2_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
     else hipLaunchKernelGGL(conv_wgrad2_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
     return DP_LAUNCH_STATUS();
+}
+
+// Weight gradient over overlapping pixel windows (see dp_conv_igemm2w): x is [N, Hi, Wi, ldx], a tap's
+// "channels" are the Cin elements starting at its pixel.  dw: fp32 [Cout][R][1][Cin].
+DP_EXPORT int dp_conv_wgrad_win(const void* dy, const void* x, void* dw, int N, int Hi, int Wi, int Cin, int ldx,
+                                int Ho, int Wo, int Cout, int R, int stride, int pad_h, int splits, hipStream_t st) {
+    if (ldx <= 0 || ldx > Cin || Cin % ldx != 0 || (ldx % 8 != 0 && ldx != 4)) return -1;
+    if ((long)(Wo - 1) * stride + Cin / ldx > Wi || (Wi * ldx) % 8 != 0) return -1;
+    t_wg_ldx = ldx;
+    const int rc = dp_conv_wgrad(dy, x, dw, N, Hi, Wi, Cin, Ho, Wo, Cout, R, 1, stride, stride, pad_h, 0, 1, 1, splits,
+                                 0, st);
+    t_wg_ldx = 0;
+    return rc;
 }

@@ -287,6 +287,27 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const bf16_raw* __res
     }
 }
 
+// Stem input packing: [N, H, W, C] (C <= 4) -> [N, H, Wp, 4] with `left` zero pixels before each row's
+// data and zeros after it: the layout the windowed stem convolution (dp_conv_igemm2w) reads — the
+// horizontal padding is physical, so a filter row is ONE contiguous 64-byte segment per output pixel.
+__global__ __launch_bounds__(256) void stem_pack_kernel(const bf16_raw* __restrict__ x, bf16_raw* __restrict__ y,
+                                                        long rows, int W, int C, int Wp, int left) {
+    const long total = rows * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const long r = i / Wp;
+        const int xs = xp - left;
+        unsigned lo = 0, hi = 0;
+        if (xs >= 0 && xs < W) {
+            const bf16_raw* src = x + (r * W + xs) * C;
+            const unsigned v0 = src[0], v1 = C > 1 ? src[1] : 0u, v2 = C > 2 ? src[2] : 0u, v3 = C > 3 ? src[3] : 0u;
+            lo = v0 | (v1 << 16);
+            hi = v2 | (v3 << 16);
+        }
+        *reinterpret_cast<uint2*>(y + i * 4) = make_uint2(lo, hi);
+    }
+}
+
 }  // namespace
 
 DP_EXPORT int dp_sgd_flat(float* p, float* g, float* m, void* p16, long n, float lr, float mu, float wd,
@@ -361,6 +382,13 @@ DP_EXPORT int dp_confusion(const void* pred, int pred_kind, const void* target, 
     else
         hipLaunchKernelGGL(confusion_kernel<long long>, dim3(grid), dim3(256), lds, st, pred, pred_kind,
                            (const long long*)target, M, C, K, ignore_index, (unsigned long long*)out_u64);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_stem_pack(const void* x, void* y, long rows, int W, int C, int Wp, int left, hipStream_t st) {
+    if (rows <= 0 || W <= 0 || C < 1 || C > 4 || left < 0 || Wp < W + left || ((uintptr_t)y & 7)) return -1;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(grid_1d(rows * Wp, 256)), dim3(256), 0, st, (const bf16_raw*)x,
+                       (bf16_raw*)y, rows, W, C, Wp, left);
     return DP_LAUNCH_STATUS();
 }
 

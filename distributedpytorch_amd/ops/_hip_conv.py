@@ -35,6 +35,8 @@ def _lib():
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
+        lib.dp_conv_igemm2w.argtypes = [V, V, V, V, V] + [I] * 19 + [V]
+        lib.dp_conv_wgrad_win.argtypes = [V, V, V] + [I] * 12 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 10 + [V]
@@ -132,7 +134,7 @@ def _save_tuned() -> None:
         os.replace(tmp, _TUNE_FILE)
 
 
-def _autotune(args, stats, reps, cout, device) -> int:
+def _autotune(args, stats, reps, cout, device, runner=None) -> int:
     lib = _lib()
     stream = B.stream_ptr()
     a = list(args)
@@ -141,6 +143,8 @@ def _autotune(args, stats, reps, cout, device) -> int:
         a[4] = B.ptr(scratch)
 
     def run(c):
+        if runner is not None:
+            return runner(a, c, stream)
         if c == 0:
             return lib.dp_conv_igemm(*a, 0, stream)
         return lib.dp_conv_igemm2(*a, c, stream)
@@ -281,7 +285,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
     return dw
 
 
-def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil) -> int:
+def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil, runner=None) -> int:
     """Split-K count of the weight-gradient kernel, measured once per problem.  How well
     tiles x splits fills the 512 resident block slots (2 per CU) decides the time as much as the
     atomic-combine traffic does (gpurun_out/s18_wgrad_sweep.log: layer-3 3x3 takes 60 us at 432
@@ -299,6 +303,8 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil) -> int:
     scratch = torch.zeros_like(dw)
 
     def run(c):
+        if runner is not None:
+            return runner(B.ptr(scratch), c, stream)
         return lib.dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(scratch), n, hi, wi, cin, ho, wo, cout, r, s,
                                  stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], c, 0, stream)
 
@@ -438,6 +444,103 @@ class _ConvIGemm(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+# ---- small-Cin stem (RGB / RGB+guidance 7x7 stride 2) ---------------------------------------------
+# Zero-padding 3 channels to the 8-channel granule makes the stem a K = 49*8 GEMM of which 3/8 is
+# real, on the first-generation kernel (3.6 ms per step at batch 128, profiles/r1_native_v10_b128.md).
+# Instead the input is packed to 4 channels with the horizontal padding physically present, and a
+# filter ROW becomes one tap: the S*4 <= 32 contiguous elements to the right of a pixel are that
+# pixel's "channels" (overlapping windows, pixel stride ldx = 4).  7 taps of 32, second-generation
+# kernels for forward and weight gradient, fused BN statistics as everywhere else.
+_STEM_WINDOW = 32
+_STEM = os.environ.get("DPAMD_STEM_WINDOW", "1") != "0"
+
+
+def stem_window_ok(x, weight, stride, padding, dilation) -> bool:
+    cout, cin, r, s = weight.shape
+    return (_STEM and cin <= 4 and s * 4 <= _STEM_WINDOW and r <= 32 and cout % 8 == 0 and s > 1
+            and tuple(dilation) == (1, 1) and stride[0] == stride[1] and not x.requires_grad)
+
+
+def _stem_pack_weights(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, R, S] -> bf16 [Cout, R, 1, 32]: element s*4 + c of row r = w[k, c, r, s]."""
+    cout, cin, r, s = w.shape
+    wp = torch.zeros((cout, r, _STEM_WINDOW // 4, 4), dtype=torch.bfloat16, device=w.device)
+    wp[:, :, :s, :cin] = w.detach().permute(0, 2, 3, 1)
+    return wp.view(cout, r, 1, _STEM_WINDOW)
+
+
+class _StemConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, with_stats):
+        cout, cin, r, s = weight.shape
+        n, _, hi, wi = x.shape
+        ho = _out_size(hi, r, stride[0], padding[0], 1)
+        wo = _out_size(wi, s, stride[1], padding[1], 1)
+        x = as_nhwc(x)
+        from . import _hip_misc
+        # row width: left padding + data, and room for the last output pixel's window; even (16-byte rows)
+        wp_px = max(padding[1] + wi, (wo - 1) * stride[1] + _STEM_WINDOW // 4)
+        wp_px += wp_px & 1
+        xp = _hip_misc.stem_pack(x, wp_px, padding[1])                       # [N, Hi, Wp, 4]
+        w32 = _stem_pack_weights(weight)
+        y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        stats = None
+        reps = 1
+        if with_stats:
+            reps = stat_replicas(n * ho * wo)
+            stats = workspace.zeros(reps * 2 * cout, x.device).view(reps, 2, cout)
+        args = (B.ptr(xp), B.ptr(w32), B.ptr(y), None, B.ptr(stats), reps, n, hi, wp_px, _STEM_WINDOW, ho, wo, cout,
+                r, 1, stride[0], 1, padding[0], 0, 1, 1, cout)
+        key = ("stem", n, hi, wp_px, ho, wo, cout, r, stride[0], padding[0], with_stats)
+        cfg = _FORCED_CFG if _FORCED_CFG else _TUNED.get(key)
+        if cfg is None:
+            def runner(a, c, stream):
+                return -2 if c == 0 else _lib().dp_conv_igemm2w(*a, c, 4, stream)
+            cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device, runner) if _AUTOTUNE else 7
+            _save_tuned()
+        B.check(_lib().dp_conv_igemm2w(*args, cfg, 4, B.stream_ptr()), "conv_igemm2w")
+        ctx.save_for_backward(xp)
+        ctx.geom = (stride, padding, (cout, cin, r, s), (n, hi, wp_px, ho, wo))
+        ctx.weight_param = weight
+        ctx.set_materialize_grads(False)
+        if with_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *rest):
+        if dy is None or not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        (xp,) = ctx.saved_tensors
+        stride, padding, (cout, cin, r, s), (n, hi, wp_px, ho, wo) = ctx.geom
+        dy = as_nhwc(dy)
+        dwp = workspace.zeros(cout * r * _STEM_WINDOW, dy.device)
+
+        def run(dst, splits, stream):
+            return _lib().dp_conv_wgrad_win(B.ptr(dy), B.ptr(xp), dst, n, hi, wp_px, _STEM_WINDOW, 4, ho, wo,
+                                            cout, r, stride[0], padding[0], splits, stream)
+        splits = 0
+        if _AUTOTUNE:
+            key = ("stem_wgrad", n, hi, wp_px, ho, wo, cout, r, stride[0], padding[0])
+            splits = _TUNED.get(key)
+            if splits is None:
+                splits = _TUNED[key] = _autotune_wgrad(dy, xp, dwp, (n, hi, wp_px, _STEM_WINDOW, ho, wo, cout, r, 1),
+                                                       stride, padding, (1, 1), run)
+                _save_tuned()
+        B.check(run(B.ptr(dwp), splits, B.stream_ptr()), "conv_wgrad_win")
+        dw = dwp.view(cout, r, _STEM_WINDOW // 4, 4)[:, :, :s, :cin].permute(0, 3, 1, 2)    # [Cout, Cin, R, S]
+        wp = ctx.weight_param
+        sink = getattr(wp, "_dpamd_grad_sink", None)
+        if sink is not None and wp.grad is not None and wp.grad.data_ptr() == sink.data_ptr():
+            sink.add_(dw)
+            notify = getattr(wp, "_dpamd_on_grad", None)
+            if notify is not None:
+                notify(wp)
+            return None, None, None, None, None
+        return None, dw.contiguous(), None, None, None
+
+
 class _DepthwiseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, w_lowp, stride, padding, dilation):
@@ -483,6 +586,8 @@ def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stat
     if w_lowp is None:
         w_lowp = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if groups == 1:
+        if bias is None and not passthrough and stem_window_ok(x, weight, stride, padding, dilation):
+            return _StemConv.apply(x, weight, stride, padding, with_stats)
         holder = getattr(x, "_dpamd_bn_holder", None) if (sole_consumer and _BN_PROLOGUE) else None
         return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats, passthrough,
                                 holder)

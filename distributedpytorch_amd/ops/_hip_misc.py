@@ -32,6 +32,7 @@ def _lib():
         lib.dp_affine_augment.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V, V, V]
         lib.dp_confusion.argtypes = [V, I, V, I, L, I, I, I, V, V]
         lib.dp_pad_channels.argtypes = [V, V, L, I, I, V]
+        lib.dp_stem_pack.argtypes = [V, V, L, I, I, I, I, V]
         _sigs_done = True
     return lib
 
@@ -260,4 +261,15 @@ def pad_channels(x: torch.Tensor, cout: int) -> torch.Tensor:
     n, c, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     B.check(_lib().dp_pad_channels(B.ptr(x), B.ptr(y), n * h * w, c, cout, B.stream_ptr()), "pad_channels")
+    return y
+
+
+def stem_pack(x: torch.Tensor, wp: int, left: int) -> torch.Tensor:
+    """channels-last bf16 [N, C<=4, H, W] -> plain [N, H, wp, 4] with ``left`` zero pixels before each
+    row's data (the windowed stem convolution's input layout, csrc/misc.hip stem_pack_kernel)."""
+    n, c, h, w = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("stem_pack: channels-last bf16 input")
+    y = torch.empty((n, h, wp, 4), dtype=torch.bfloat16, device=x.device)
+    B.check(_lib().dp_stem_pack(B.ptr(x), B.ptr(y), n * h, w, c, wp, left, B.stream_ptr()), "stem_pack")
     return y
