@@ -27,7 +27,10 @@
 
 namespace {
 
-constexpr int BK = 64;                       // K elements per step (128 B per operand row)
+// K elements per step: 64 (128-B operand rows) or 32 (64-B rows).  At 256x256 two 64-wide stages fill
+// the LDS, so the ring is only 2 deep and every step drains the stage it just issued (vmcnt(0)): the
+// DMA latency is exposed once per step.  32-wide stages make the same 128 KiB a 4-deep ring — two
+// stages stay in flight across every barrier.
 constexpr unsigned kOOB = 0x80000000u;       // byte offset beyond any descriptor (tensors < 2 GiB)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
@@ -83,15 +86,26 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT>
+// read/source swizzle of a tile row's 16-byte chunks (an involution applied on both sides; the DMA
+// destination stays linear).  128-B rows: 2 rows per 256-B bank row -> XOR (row>>1)&7.  64-B rows: 4 rows
+// per bank row, and a ds_read_b128 lane group pairs rows {0-3,12-15} of one chunk column with rows {4-11}
+// of the neighbouring one (MI355X_MICROARCH.md, LDS), which the table {0,3,2,1}[(row>>2)&3] keeps apart.
+template <int BK>
+__device__ __forceinline__ int chunk_swz(int row) {
+    return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2Args p) {
     constexpr int T = 64 * WGM * WGN;
-    constexpr int RPR = T / 8;                           // tile rows filled per load round
+    constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
+    constexpr int ROWB = BK * 2;                         // bytes per tile row
+    constexpr int RPR = T / CPR;                         // tile rows filled per load round
     constexpr int AR = BM / RPR, BR = BN / RPR;          // load rounds per stage
     constexpr int L = AR + BR;                           // LDS-DMA instructions per thread per stage
     constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile: pixels × channels
     constexpr int MI = WTM / 16, NI = WTN / 16;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int C_LD = BN * 2 + 8;                     // epilogue row stride: 16 rows -> 32 distinct banks
     static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must be whole load rounds");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be whole 16x16 MFMA tiles");
@@ -118,9 +132,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
     // ---- per-thread load geometry: lane -> (row rr of the round, physical 16-B chunk pc) ----
-    const int pc = tid & 7;
-    const int rr = tid >> 3;
-    const int lc = pc ^ ((rr >> 1) & 7);     // logical chunk fetched (source-side swizzle)
+    const int pc = tid & (CPR - 1);
+    const int rr = tid / CPR;
+    const int lc = pc ^ chunk_swz<BK>(rr);   // logical chunk fetched (source-side swizzle)
     unsigned a_voff[AR], a_mask[AR];
     {
         const int sdm = (1 << p.sdl) - 1;
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     int kr = 0, ks = 0, kc = 0;
     const int sdr = (1 << p.sdl) - 1;
     auto issue_stage = [&](int buf) {
-        unsigned char* abase = smem + buf * STAGE + wave * (8 * 128);
+        unsigned char* abase = smem + buf * STAGE + wave * 1024;       // one wave-instruction fills 1 KiB
         unsigned char* bbase = abase + A_BYTES;
         const unsigned w_soff = (unsigned)(((kr * p.S + ks) * p.Cin + kc * BK) * 2);
         if (UNIT) {
@@ -183,10 +197,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             if (p.ctail) {
                 const bool cv = lc * 8 < p.Cin - kc * BK;
 #pragma unroll
-                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * 128), cv ? a_voff[i] : kOOB, a_soff);
+                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * ROWB), cv ? a_voff[i] : kOOB, a_soff);
             } else {
 #pragma unroll
-                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * 128), a_voff[i], a_soff);
+                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * ROWB), a_voff[i], a_soff);
             }
         } else {
             const int cdy = (kr * p.dil_h + sdr) >> p.sdl, cdx = (ks * p.dil_w + sdr) >> p.sdl;   // ceil(tap / sdiv)
@@ -197,11 +211,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             for (int i = 0; i < AR; ++i) {
                 const bool ok = ((a_mask[i] & tapbit) != 0) & cv;
                 // the sum is formed per lane: the base may be "negative" (padding) and only base+tap is in range
-                lds_dma16(rx, abase + i * (RPR * 128), ok ? a_voff[i] + a_soff : kOOB, 0);
+                lds_dma16(rx, abase + i * (RPR * ROWB), ok ? a_voff[i] + a_soff : kOOB, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) lds_dma16(rw, bbase + i * (RPR * 128), b_voff[i], w_soff);
+        for (int i = 0; i < BR; ++i) lds_dma16(rw, bbase + i * (RPR * ROWB), b_voff[i], w_soff);
         if (++kc == p.csteps) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
     };
 
@@ -214,10 +228,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
 
     const int wm = wave / WGN, wn = wave % WGN;
     const int l15 = lane & 15, q = lane >> 4;
-    const int fsw = l15 >> 1;                                   // read-side swizzle (tile bases are multiples of 16)
-    const int x_row_off = (wm * WTM + l15) * 128;
-    const int w_row_off = A_BYTES + (wn * WTN + l15) * 128;
-    const int ch0 = ((q ^ fsw) << 4), ch1 = (((4 + q) ^ fsw) << 4);
+    const int fsw = chunk_swz<BK>(l15);                         // read-side swizzle (tile bases are multiples of 16)
+    const int x_row_off = (wm * WTM + l15) * ROWB;
+    const int w_row_off = A_BYTES + (wn * WTN + l15) * ROWB;
+    const int ch0 = ((q ^ fsw) << 4), ch1 = (((4 + q) ^ fsw) << 4);      // ch1: second half of a 64-wide step
 
     // ---- prologue: NST-1 stages in flight ----
     const int ksteps = p.ksteps;
@@ -241,15 +255,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         }
         const unsigned char* St = smem + buf * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             const int chunk = kk == 0 ? ch0 : ch1;
             bf16x8 wf[NI], xf[MI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[ni] = *reinterpret_cast<const bf16x8*>(St + w_row_off + ni * (16 * 128) + chunk);
+                wf[ni] = *reinterpret_cast<const bf16x8*>(St + w_row_off + ni * (16 * ROWB) + chunk);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                xf[mi] = *reinterpret_cast<const bf16x8*>(St + x_row_off + mi * (16 * 128) + chunk);
+                xf[mi] = *reinterpret_cast<const bf16x8*>(St + x_row_off + mi * (16 * ROWB) + chunk);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -425,26 +439,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MINW>
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW, int BK = 64>
 int launch2(Conv2Args& p, bool unit, hipStream_t st) {
     constexpr int T = 64 * WGM * WGN;
+    p.csteps = (p.Cin + BK - 1) / BK;
+    p.ksteps = p.R * p.S * p.csteps;
+    p.ctail = (p.Cin % BK) != 0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const long nwg = (long)p.tiles_m * p.tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return -4;
-    constexpr int stage_bytes = NST * (BM + BN) * 128;
+    constexpr int stage_bytes = NST * (BM + BN) * BK * 2;
     constexpr int epi_bytes = BM * (BN * 2 + 8) + WGM * 2 * BN * 4;
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (unit) {
-        auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true>;
+        auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK>;
         if (lds > 64 * 1024) {
             static bool once = false;
             if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
     } else {
-        auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false>;
+        auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false, BK>;
         if (lds > 64 * 1024) {
             static bool once = false;
             if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
@@ -459,7 +476,7 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
 // cfg: 1 = 128x128 4-wave 2-stage   2 = 128x128 4-wave 4-stage   3 = 256x128 8-wave 3-stage
 //      4 = 128x256 8-wave 3-stage   5 = 256x256 8-wave 2-stage   6 = 256x64 8-wave 3-stage
 //      7 = 128x64 4-wave 3-stage    8 = 160x128 / 9 = 192x128 4-wave 2-stage (tile-count quantisation)
-//      10 = 256x128 8-wave 2-stage
+//      10 = 256x128 8-wave 2-stage   11 = 256x256 / 12 = 256x128 8-wave, 13 = 128x64 4-wave: 32-wide K steps, 4-stage ring
 // Returns -2 for shapes this kernel does not take (R*S > 32, bias together with stats, Cout % 8):
 // the caller then uses conv_igemm.hip.
 DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
@@ -515,9 +532,6 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.smul = smul; p.sdl = sdiv == 1 ? 0 : (sdiv == 2 ? 1 : 2);
     p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
     p.ldy = ldy;
-    p.csteps = (Cin + BK - 1) / BK;
-    p.ksteps = R * S * p.csteps;
-    p.ctail = (Cin % BK) != 0;
     p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
     const bool unit = (R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && sdiv == 1 && ldx == Cin);
     switch (cfg) {
@@ -531,6 +545,9 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
         case 8: return launch2<160, 128, 2, 2, 2, 2>(p, unit, st);
         case 9: return launch2<192, 128, 2, 2, 2, 2>(p, unit, st);
         case 10: return launch2<256, 128, 4, 2, 2, 2>(p, unit, st);
+        case 11: return launch2<256, 256, 2, 4, 4, 2, 32>(p, unit, st);
+        case 12: return launch2<256, 128, 4, 2, 4, 2, 32>(p, unit, st);
+        case 13: return launch2<128, 64, 2, 2, 4, 1, 32>(p, unit, st);
         default: return -2;
     }
 }

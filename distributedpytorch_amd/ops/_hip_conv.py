@@ -114,6 +114,8 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
 # statistics go to a scratch buffer meanwhile), the fastest is cached for the life of the process.
 _FORCED_CFG = int(os.environ["DPAMD_CONV_CFG"]) if "DPAMD_CONV_CFG" in os.environ else None
 _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
+# 11-13 (32-wide K steps, 4-stage ring) are selectable but not tried: measured 8-10 % slower than their
+# 64-wide 2-stage counterparts on every R101 layer at batch 128 (profiles/r1_conv_cfg_sweep_b128.log)
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 0)
 _TUNED: dict = {}
 # optional cross-process cache of the measured choices (JSON): set DPAMD_CONV_TUNE_FILE
@@ -134,7 +136,7 @@ def _save_tuned() -> None:
         os.replace(tmp, _TUNE_FILE)
 
 
-def _autotune(args, stats, reps, cout, device, runner=None) -> int:
+def _autotune(args, stats, reps, cout, device, runner=None, candidates=None) -> int:
     lib = _lib()
     stream = B.stream_ptr()
     a = list(args)
@@ -150,7 +152,7 @@ def _autotune(args, stats, reps, cout, device, runner=None) -> int:
         return lib.dp_conv_igemm2(*a, c, stream)
 
     timed = []
-    for c in _CANDIDATES:
+    for c in (candidates or _CANDIDATES):
         st = run(c)                      # warm-up (also tells whether the kernel takes this shape)
         if st == -2:
             continue
@@ -496,7 +498,8 @@ class _StemConv(torch.autograd.Function):
         if cfg is None:
             def runner(a, c, stream):
                 return -2 if c == 0 else _lib().dp_conv_igemm2w(*a, c, 4, stream)
-            cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device, runner) if _AUTOTUNE else 7
+            cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device, runner,
+                                          (7, 13, 6, 1, 3, 12)) if _AUTOTUNE else 7
             _save_tuned()
         B.check(_lib().dp_conv_igemm2w(*args, cfg, 4, B.stream_ptr()), "conv_igemm2w")
         ctx.save_for_backward(xp)

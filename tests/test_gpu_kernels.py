@@ -142,7 +142,7 @@ IGEMM2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("case", IGEMM2_CASES)
 def test_igemm2_all_tile_configs(case, cfg):
     """csrc/conv_igemm2.hip: every tile configuration, forward + data-gradient + fused statistics,
