@@ -149,6 +149,33 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const bf16_raw* __re
     block_reduce_atomic<16>(m, acc, smem, sum, sq, C);
 }
 
+// Dropout fused into the BN+ReLU pass (the decoder's conv-BN-ReLU-Dropout): the keep decision of an
+// element is a counter-based hash of (element index, seed), 16 bits per element, so the backward
+// kernels RECOMPUTE it — no mask tensor, no separate dropout / masked-scale passes over the largest
+// activations.  thr = round(p·65536) (0 = off), scale = 1 / (1 − thr/65536).
+struct Drop { unsigned thr; float scale; unsigned seed_lo, seed_hi; };
+
+__device__ __forceinline__ unsigned drop_hash(unsigned lo, unsigned hi, const Drop& d) {
+    unsigned x = lo ^ d.seed_lo;
+    x *= 0xcc9e2d51u; x = (x << 15) | (x >> 17); x *= 0x1b873593u;
+    x ^= (hi ^ d.seed_hi) * 0x85ebca6bu;
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;      // murmur3 fmix32
+    return x;
+}
+
+// keep bits of the 8 elements of 16-byte chunk q (bit j = element j)
+__device__ __forceinline__ unsigned drop_keep8(long q, const Drop& d) {
+    const unsigned long long e = (unsigned long long)q * 4ull;
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned h = drop_hash((unsigned)(e + k), (unsigned)((e + k) >> 32), d);
+        keep |= (unsigned)((h & 0xffffu) >= d.thr) << (2 * k);
+        keep |= (unsigned)((h >> 16) >= d.thr) << (2 * k + 1);
+    }
+    return keep;
+}
+
 struct ApplyArgs {
     const bf16_raw* x; const bf16_raw* res; bf16_raw* y;
     long M; int C;
@@ -160,6 +187,7 @@ struct ApplyArgs {
     int relu;
     int nrep;   // statistics replicas: sum/sq are [nrep][2][C] when produced by the conv epilogue
     long rep_stride;
+    Drop drop;
 };
 
 template <bool FROM_STATS>
@@ -224,6 +252,14 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
             if (a.relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
             f0[j] = y0; f1[j] = y1;
         }
+        if (a.drop.thr) {
+            const unsigned k0 = drop_keep8(q0, a.drop), k1 = drop_keep8(q1, a.drop);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f0[j] = (k0 >> j) & 1u ? f0[j] * a.drop.scale : 0.f;
+                f1[j] = (k1 >> j) & 1u ? f1[j] * a.drop.scale : 0.f;
+            }
+        }
         stg16(a.y, q0, pack8(f0));
         if (second) stg16(a.y, q1, pack8(f1));
     }
@@ -239,11 +275,13 @@ struct BwdArgs {
     float inv_count;
     float* gw_sink; float* gb_sink;        // optional: += local Σdy'·x̂ / Σdy' (parameter-gradient arenas)
     const float* lsdy; const float* lsdyx; // local (pre all-reduce) sums feeding the sinks
-    int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0
+    int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0, 3: as 2, and the fused
+                    //    dropout's keep bit recomputed from the hash (dy' = keep·relu'·dy·scale)
+    Drop drop;
 };
 
 __device__ __forceinline__ void masked_dy(const BwdArgs& a, int mode, const float* sc, const float* sh,
-                                          const float* xf, const uint4& yv, float* dyf) {
+                                          const float* xf, const uint4& yv, float* dyf, long q) {
     if (mode == 1) {
         float yf[8];
         unpack8(yv, yf);
@@ -252,6 +290,11 @@ __device__ __forceinline__ void masked_dy(const BwdArgs& a, int mode, const floa
     } else if (mode == 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dyf[j] = fmaf(xf[j], sc[j], sh[j]) > 0.f ? dyf[j] : 0.f;
+    } else if (mode == 3) {
+        const unsigned keep = drop_keep8(q, a.drop);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dyf[j] = (fmaf(xf[j], sc[j], sh[j]) > 0.f && ((keep >> j) & 1u)) ? dyf[j] * a.drop.scale : 0.f;
     }
 }
 
@@ -285,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
             if (a.mask_mode == 1) { y0 = ldg16(a.y, q0); y1 = ldg16(a.y, q1); }
             float df[8], xf[8];
             unpack8(d0, df); unpack8(x0, xf);
-            masked_dy(a, a.mask_mode, sc, sh, xf, y0, df);
+            masked_dy(a, a.mask_mode, sc, sh, xf, y0, df, q0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 acc[j] += df[j];
@@ -293,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
             }
             if (second) {
                 unpack8(d1, df); unpack8(x1, xf);
-                masked_dy(a, a.mask_mode, sc, sh, xf, y1, df);
+                masked_dy(a, a.mask_mode, sc, sh, xf, y1, df, q1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     acc[j] += df[j];
@@ -349,14 +392,14 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
         if (a.mask_mode == 1) { y0 = ldg16(a.y, q0); y1 = ldg16(a.y, q1); }
         float df[8], xf[8], o[8];
         unpack8(d0, df); unpack8(x0, xf);
-        masked_dy(a, a.mask_mode, sc, sh, xf, y0, df);
+        masked_dy(a, a.mask_mode, sc, sh, xf, y0, df, q0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fmaf(ka[j], df[j], fmaf(kb[j], xf[j], kc[j]));
         stg16(a.dx, q0, pack8(o));
         if (a.dres) stg16(a.dres, q0, pack8(df));
         if (second) {
             unpack8(d1, df); unpack8(x1, xf);
-            masked_dy(a, a.mask_mode, sc, sh, xf, y1, df);
+            masked_dy(a, a.mask_mode, sc, sh, xf, y1, df, q1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaf(ka[j], df[j], fmaf(kb[j], xf[j], kc[j]));
             stg16(a.dx, q1, pack8(o));
@@ -387,6 +430,15 @@ inline dim3 grid_reduce(long M, int C) {
     return dim3((unsigned)splits, (unsigned)slabs, 1);
 }
 
+// set by dp_bn_set_dropout for the NEXT apply_stats / bwd_reduce / bwd_apply launch of this thread
+thread_local Drop t_drop = {0u, 1.f, 0u, 0u};
+
+inline Drop take_drop() {
+    const Drop d = t_drop;
+    t_drop = Drop{0u, 1.f, 0u, 0u};
+    return d;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -398,6 +450,16 @@ DP_EXPORT int dp_bn_stats(const void* x, long M, int C, float* sum, float* sq, h
     hipLaunchKernelGGL(bn_stats_kernel, grid_reduce(M, C), dim3(kThreads), 0, st,
                        (const bf16_raw*)x, M, C, sum, sq);
     return DP_LAUNCH_STATUS();
+}
+
+// thr16: round(p * 65536) in [1, 65535]; consumed (and cleared) by the next launch listed above
+DP_EXPORT int dp_bn_set_dropout(unsigned thr16, unsigned long long seed) {
+    if (thr16 == 0 || thr16 > 65535u) return -1;
+    t_drop.thr = thr16;
+    t_drop.scale = 65536.f / (float)(65536u - thr16);
+    t_drop.seed_lo = (unsigned)seed;
+    t_drop.seed_hi = (unsigned)(seed >> 32);
+    return 0;
 }
 
 DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M, int C, const float* sum,
@@ -412,6 +474,7 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
     a.inv_count = 1.f / count; a.eps = eps; a.momentum = momentum;
     a.unbias = count > 1.f ? count / (count - 1.f) : 1.f;
     a.relu = relu; a.nrep = nrep < 1 ? 1 : nrep; a.rep_stride = rep_stride;
+    a.drop = take_drop();
     hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
@@ -434,6 +497,8 @@ DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, lon
     a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y; a.M = M; a.C = C;
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias;
     a.out_sdy = out_sdy; a.out_sdyx = out_sdyx; a.mask_mode = mask_mode;
+    a.drop = take_drop();
+    if (mask_mode == 3 && a.drop.thr == 0) return -1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid_reduce(M, C), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
@@ -449,6 +514,8 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias; a.sdy = sdy; a.sdyx = sdyx;
     a.inv_count = 1.f / count; a.mask_mode = mask_mode;
     a.gw_sink = gw_sink; a.gb_sink = gb_sink; a.lsdy = lsdy; a.lsdyx = lsdyx;
+    a.drop = take_drop();
+    if (mask_mode == 3 && a.drop.thr == 0) return -1;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }

@@ -71,8 +71,7 @@ class ASPP(nn.Module):
         pooled = self.global_avg_pool(x)
         pooled = pooled.expand(-1, -1, h, w)  # align_corners bilinear of a 1×1 map = broadcast
         y = torch.cat([b1, b2, b3, b4, pooled], dim=1)
-        y = conv_bn_act(self.conv1, self.bn1, y, relu=True)
-        return F.dropout(y, self.p_drop, self.training)
+        return conv_bn_act(self.conv1, self.bn1, y, relu=True, dropout=self.p_drop)
 
 
 class _LastConv(nn.Module):
@@ -87,10 +86,9 @@ class _LastConv(nn.Module):
         self.add_module("8", Conv2d(mid, num_classes, 1))
 
     def forward(self, x, training: bool):
-        x = conv_bn_act(getattr(self, "0"), getattr(self, "1"), x, relu=True)
-        x = F.dropout(x, 0.5, training)
-        x = conv_bn_act(getattr(self, "4"), getattr(self, "5"), x, relu=True)
-        x = F.dropout(x, 0.1, training)
+        # conv-BN-ReLU-Dropout: the dropout runs inside the BN kernels (ops.batchnorm, csrc/bn_relu.hip)
+        x = conv_bn_act(getattr(self, "0"), getattr(self, "1"), x, relu=True, dropout=0.5)
+        x = conv_bn_act(getattr(self, "4"), getattr(self, "5"), x, relu=True, dropout=0.1)
         return getattr(self, "8")(x)
 
 

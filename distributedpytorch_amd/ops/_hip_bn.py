@@ -26,6 +26,7 @@ def _lib():
             [c_int, c_void_p]
         lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int] + \
             [c_void_p] * 5
+        lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         _sigs_done = True
     return lib
 
@@ -82,8 +83,15 @@ def apply(x, scale, shift, residual, relu):
     return y
 
 
+def _arm_dropout(dropout) -> None:
+    """``dropout`` = (thr16, seed): the NEXT bn launch of this thread applies / recomputes the fused
+    dropout (csrc/bn_relu.hip, struct Drop)."""
+    if dropout is not None:
+        B.check(_lib().dp_bn_set_dropout(int(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF), "bn_set_dropout")
+
+
 def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var, count, eps, momentum, relu,
-                     replicas=None):
+                     replicas=None, dropout=None):
     """Training form: finalises mean/invstd/running stats inside the apply kernel.
     ``replicas``: optional fp32 [R, 2, C] partial statistics from the conv epilogue (then ``s``/``ss``
     are ignored and the kernel sums the R replicas itself).  Returns (y, mean, invstd)."""
@@ -105,6 +113,7 @@ def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var
         _check_act(residual, "residual", x)
     y = torch.empty_like(x)
     mi = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    _arm_dropout(dropout)
     B.check(_lib().dp_bn_apply_stats(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(s), B.ptr(ss),
                                      B.ptr(weight), B.ptr(bias), B.ptr(mi[0]), B.ptr(mi[1]),
                                      B.ptr(running_mean), B.ptr(running_var), float(count), float(eps),
@@ -113,7 +122,7 @@ def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var
     return y, mi[0], mi[1]
 
 
-def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode):
+def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode, dropout=None):
     dy = as_nhwc(dy)
     _check_act(x, "x"); _check_act(dy, "dy", x)
     M, C = _mc(x)
@@ -122,6 +131,9 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode):
     for t, nm in ((mean, "mean"), (invstd, "invstd"), (weight, "weight"), (bias, "bias")):
         _check_vec(t, C, nm)
     buf = workspace.zeros(2 * C, x.device).view(2, C)
+    if (mask_mode == 3) != (dropout is not None):
+        raise ValueError("mask_mode 3 <=> fused dropout")
+    _arm_dropout(dropout)
     B.check(_lib().dp_bn_bwd_reduce(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), M, C,
                                     B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                     B.ptr(buf[0]), B.ptr(buf[1]), int(mask_mode), B.stream_ptr()), "bn_bwd_reduce")
@@ -129,7 +141,7 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode):
 
 
 def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres,
-              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None):
+              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None, dropout=None):
     dy = as_nhwc(dy)
     _check_act(x, "x"); _check_act(dy, "dy", x)
     M, C = _mc(x)
@@ -143,6 +155,9 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
             _check_vec(t, C, nm)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if need_dres else None
+    if (mask_mode == 3) != (dropout is not None):
+        raise ValueError("mask_mode 3 <=> fused dropout")
+    _arm_dropout(dropout)
     B.check(_lib().dp_bn_bwd_apply(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), B.ptr(dx),
                                    B.ptr(dres), M, C, B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                    B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.ptr(gw_sink),

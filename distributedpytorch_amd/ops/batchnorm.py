@@ -23,7 +23,11 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import _backend as B
+
+_FUSE_DROPOUT = os.environ.get("DPAMD_FUSE_DROPOUT", "1") != "0"
 
 
 # --------------------------------------------------------------------------------------
@@ -95,7 +99,8 @@ def _group_active(group) -> bool:
 class _BatchNormActTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group,
-                conv_stats=None, holder=None):
+                conv_stats=None, holder=None, dropout=None):
+        """``dropout`` = (thr16, seed) or None: dropout fused behind the ReLU (HIP path, no residual)."""
         C = x.shape[1]
         local_count = x.numel() // C
         hip = B.use_hip(x)
@@ -141,8 +146,11 @@ class _BatchNormActTrain(torch.autograd.Function):
             w = weight.detach().float().contiguous() if weight is not None else None
             b = bias.detach().float().contiguous() if bias is not None else None
             y, mean, invstd = _hip_bn.apply_from_stats(x, s, ss, w, b, residual, running_mean, running_var,
-                                                       count, eps, momentum, relu, replicas)
+                                                       count, eps, momentum, relu, replicas, dropout)
             mask_mode = 0 if not relu else (1 if residual is not None else 2)
+            if dropout is not None:
+                assert relu and residual is None
+                mask_mode, holder = 3, None
             ctx.save_for_backward(x, y if mask_mode == 1 else None, w, b, mean, invstd)
             ctx.mask_mode = mask_mode
             if holder is not None and relu:
@@ -168,6 +176,7 @@ class _BatchNormActTrain(torch.autograd.Function):
             y = _t_apply(x, scale, shift, residual, relu)
             ctx.save_for_backward(x, y if relu else None, w, b, mean, invstd)
         ctx.holder = holder if (hip and holder) else None
+        ctx.dropout = dropout if hip else None
         ctx.hip, ctx.relu, ctx.count, ctx.sync, ctx.pg = hip, relu, count, sync, pg
         ctx.has_res = residual is not None
         ctx.has_affine = weight is not None
@@ -193,7 +202,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 fused_dres, need_dres = dy, False
         elif ctx.hip:
             from . import _hip_bn
-            sdy, sdyx = _hip_bn.bwd_reduce(dy, x, y, mean, invstd, w, b, ctx.mask_mode)
+            sdy, sdyx = _hip_bn.bwd_reduce(dy, x, y, mean, invstd, w, b, ctx.mask_mode, ctx.dropout)
         else:
             sdy, sdyx = _t_bwd_reduce(dy, x, y, mean, invstd, ctx.relu)
         g_sdy, g_sdyx = sdy, sdyx
@@ -216,17 +225,17 @@ class _BatchNormActTrain(torch.autograd.Function):
                 # affine gradients are added into the gradient arena by the same kernel
                 from . import _hip_bn
                 dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                             mask_mode, need_dres, gw, gb, sdy, sdyx)
+                                             mask_mode, need_dres, gw, gb, sdy, sdyx, ctx.dropout)
                 if fused_dres is not None:
                     dres = fused_dres
                 for prm in (wp, bp):
                     notify = getattr(prm, "_dpamd_on_grad", None)
                     if notify is not None:
                         notify(prm)
-                return dx, None, None, dres, None, None, None, None, None, None, None, None
+                return dx, None, None, dres, None, None, None, None, None, None, None, None, None
             from . import _hip_bn
             dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                         mask_mode, need_dres)
+                                         mask_mode, need_dres, dropout=ctx.dropout)
             if fused_dres is not None:
                 dres = fused_dres
         else:
@@ -235,7 +244,7 @@ class _BatchNormActTrain(torch.autograd.Function):
         # clone: the sums may live in the per-step scratch pool, autograd may keep the tensor as .grad
         dweight = sdyx.to(ctx.wdtype, copy=True) if ctx.has_affine else None
         dbias = sdy.to(ctx.wdtype, copy=True) if ctx.has_affine else None
-        return dx, dweight, dbias, dres, None, None, None, None, None, None, None, None
+        return dx, dweight, dbias, dres, None, None, None, None, None, None, None, None, None
 
 
 class _BatchNormActFrozen(torch.autograd.Function):
@@ -269,25 +278,49 @@ class _BatchNormActFrozen(torch.autograd.Function):
         return dx, None, None, dres, None
 
 
+_drop_calls = 0
+
+
+def _dropout_key(p: float):
+    """(thr16, seed) of one fused-dropout call: the keep probability quantised to 1/65536 and a seed
+    derived from torch's seed, the rank and a per-process call counter — a kernel ARGUMENT, no device
+    RNG state is read, nothing is launched."""
+    global _drop_calls
+    _drop_calls += 1
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + _drop_calls * 0x94D049BB133111EB)
+    thr = min(65535, max(1, int(round(p * 65536))))
+    return thr, seed & 0xFFFFFFFFFFFFFFFF
+
+
 def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, training: bool,
                    momentum: float = 0.1, eps: float = 1e-5, relu: bool = False,
                    residual: Optional[torch.Tensor] = None, group=False,
-                   conv_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``act(BN(x) + residual)``.  ``group``: ``False`` = local statistics, ``True`` = default
-    process group, or a ``ProcessGroup`` = statistics all-reduced over that group."""
+                   conv_stats: Optional[torch.Tensor] = None, dropout: float = 0.0) -> torch.Tensor:
+    """``drop(act(BN(x) + residual))``.  ``group``: ``False`` = local statistics, ``True`` = default
+    process group, or a ``ProcessGroup`` = statistics all-reduced over that group.  ``dropout``: the
+    probability of an ``F.dropout`` behind the activation; on the HIP training path (ReLU, no residual)
+    it runs inside the BN kernels (forward and backward), elsewhere as a separate op."""
     if B.get_backend() == "torch" and not _group_active(group):
         # stock baseline: MIOpen / ATen batch-norm followed by separate add and ReLU
         y = F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
+        y = F.relu(y) if relu else y
+        return F.dropout(y, dropout, True) if dropout > 0.0 else y
     if training:
         holder = {} if (relu and B.use_hip(x)) else None
+        fuse_drop = dropout > 0.0 and relu and residual is None and B.use_hip(x) and _FUSE_DROPOUT
         y = _BatchNormActTrain.apply(x, weight, bias, residual, running_mean, running_var,
-                                     momentum, eps, relu, group, conv_stats, holder)
-        if holder:
+                                     momentum, eps, relu, group, conv_stats, holder,
+                                     _dropout_key(dropout) if fuse_drop else None)
+        if dropout > 0.0 and not fuse_drop:
+            return F.dropout(y, dropout, True)
+        if holder and not fuse_drop:
             y._dpamd_bn_holder = holder      # read by ops._hip_conv.conv2d(..., sole_consumer=True)
         return y
+    if dropout > 0.0:
+        raise ValueError("dropout with frozen / eval statistics: apply F.dropout on the result")
     invstd = torch.rsqrt(running_var.float() + eps)
     scale = invstd * (weight.float() if weight is not None else 1.0)
     shift = (bias.float() if bias is not None else 0.0) - running_mean.float() * scale
@@ -315,13 +348,18 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                stats: Optional[torch.Tensor] = None):
+                stats: Optional[torch.Tensor] = None, dropout: float = 0.0):
+        """``dropout``: probability of a dropout behind the activation, applied in training mode only
+        (fused into the BN kernels on the HIP path)."""
         training = self.training and not self.frozen
+        if dropout > 0.0 and not training:
+            y = self.forward(x, relu, residual, stats)
+            return F.dropout(y, dropout, self.training)
         group = False
         if self.sync and training:
             group = self.process_group if self.process_group is not None else True
         return batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                              training, self.momentum, self.eps, relu, residual, group, stats)
+                              training, self.momentum, self.eps, relu, residual, group, stats, dropout)
 
     def extra_repr(self) -> str:
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "

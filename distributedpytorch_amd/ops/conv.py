@@ -138,9 +138,13 @@ class Conv2d(nn.Module):
 
 
 def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
-                residual: Optional[torch.Tensor] = None, passthrough: bool = False, sole_consumer: bool = False):
+                residual: Optional[torch.Tensor] = None, passthrough: bool = False, sole_consumer: bool = False,
+                dropout: float = 0.0):
     """``act(BN(conv(x)) + residual)``.  On the GPU path the batch statistics come out of the conv
     kernel's epilogue (no separate statistics pass over the activation).
+
+    ``dropout``: probability of a dropout behind the activation (training only), run inside the BN
+    kernels on the GPU path (ops.batchnorm).
 
     ``passthrough=True`` returns ``(out, x')`` where ``x'`` is ``x`` routed through the convolution's
     autograd node: use ``x'`` as the block's identity and the skip-path gradient is added inside the
@@ -151,12 +155,12 @@ def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
             y, stats, skip = conv(x, with_stats=True, passthrough=True, sole_consumer=sole_consumer)
         else:
             y, stats = conv(x, with_stats=True, sole_consumer=sole_consumer)
-        out = bn(y, relu=relu, residual=residual, stats=stats)
+        out = bn(y, relu=relu, residual=residual, stats=stats, dropout=dropout)
     elif pt:
         y, skip = conv(x, passthrough=True, sole_consumer=sole_consumer)
-        out = bn(y, relu=relu, residual=residual)
+        out = bn(y, relu=relu, residual=residual, dropout=dropout)
     else:
-        out = bn(conv(x, sole_consumer=sole_consumer), relu=relu, residual=residual)
+        out = bn(conv(x, sole_consumer=sole_consumer), relu=relu, residual=residual, dropout=dropout)
     if passthrough:
         return out, (skip if pt else x)
     return out

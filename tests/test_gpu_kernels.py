@@ -292,6 +292,44 @@ def test_batchnorm_train(shape, relu, res):
     assert _rel(got[5], ref[5]) < 1e-2 and _rel(got[6], ref[6]) < 1e-2
 
 
+@pytest.mark.parametrize("p", [0.5, 0.1])
+@pytest.mark.parametrize("shape", [(2, 64, 33, 31), (3, 256, 17, 17)])
+def test_batchnorm_fused_dropout(shape, p):
+    """Dropout inside the BN+ReLU kernels (csrc/bn_relu.hip, struct Drop): the kept fraction, the
+    1/(1-p) scale, and a backward that recomputes the SAME mask from the hash — checked against
+    torch autograd run with the mask read back from the fused output."""
+    torch.manual_seed(5)
+    n, c, h, w = shape
+    x = _nhwc(_bf(torch.randn(shape, device=DEV) * 2 + 0.3))
+    bn = ops.BatchNorm2d(c).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    xh = x.clone().requires_grad_(True)
+    y = bn(xh, relu=True, dropout=p)
+    gy = _nhwc(_bf(torch.randn_like(y)))
+    y.backward(gy)
+
+    xr = x.float().requires_grad_(True)
+    wr = bn.weight.detach().clone().requires_grad_(True)
+    br = bn.bias.detach().clone().requires_grad_(True)
+    act = F.relu(F.batch_norm(xr, None, None, wr, br, True, 0.1, bn.eps))
+    live = act.detach() > 1e-3                         # away from the ReLU edge (bf16 rounding of y)
+    keep = (y.detach().float() != 0)
+    frac = float(keep[live].float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    p_eff = round(p * 65536) / 65536
+    ref = act * keep / (1 - p_eff)
+    assert _rel(y, ref) < 1.5e-2
+    ref.backward(gy.float())
+    assert _rel(xh.grad, xr.grad) < 2e-2
+    assert _rel(bn.weight.grad, wr.grad) < 1e-2
+    assert _rel(bn.bias.grad, br.grad) < 1e-2
+    # a second call draws a different mask
+    y2 = bn(x, relu=True, dropout=p)
+    assert float(((y2 != 0) != (y.detach() != 0)).float().mean()) > 0.05
+
+
 def test_batchnorm_eval_and_frozen():
     torch.manual_seed(3)
     c = 64
@@ -469,6 +507,7 @@ def test_model_step_matches_stock_path():
     x = torch.randn(2, 3, 129, 129, device=DEV)
     y = torch.randint(0, 21, (2, 129, 129), device=DEV)
     y[:, :5] = 255
+    from distributedpytorch_amd.ops import batchnorm as bn_mod
     losses = {}
     for backend in ("torch", "auto"):
         torch.manual_seed(11)
@@ -479,13 +518,15 @@ def test_model_step_matches_stock_path():
         # small shape on ROCm 7.0/7.2 — host-side crash inside F.batch_norm, observed on MI355X)
         prev = torch.backends.cudnn.enabled
         torch.backends.cudnn.enabled = False
+        prev_fuse, bn_mod._FUSE_DROPOUT = bn_mod._FUSE_DROPOUT, False     # torch's RNG on both sides: same masks
         try:
             with ops.backend(backend):
                 out = m(_nhwc(_bf(x)))
                 loss = ops.softmax_cross_entropy(out, y)
         finally:
             torch.backends.cudnn.enabled = prev
-        losses[backend] = float(loss)
+            bn_mod._FUSE_DROPOUT = prev_fuse
+        losses[backend] = float(loss.detach())
     assert abs(losses["auto"] - losses["torch"]) < 0.05 * abs(losses["torch"])
 
 
