@@ -188,6 +188,8 @@ struct ApplyArgs {
     int nrep;   // statistics replicas: sum/sq are [nrep][2][C] when produced by the conv epilogue
     long rep_stride;
     Drop drop;
+    long y_ld8;   // output row stride in 16-byte chunks (C/8, or more when y is a channel slice of a
+                  // wider concat buffer: the producer writes its slice in place, no cat kernel)
 };
 
 template <bool FROM_STATS>
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
                 f1[j] = (k1 >> j) & 1u ? f1[j] * a.drop.scale : 0.f;
             }
         }
-        stg16(a.y, q0, pack8(f0));
-        if (second) stg16(a.y, q1, pack8(f1));
+        stg16(a.y, r * a.y_ld8 + m.cg, pack8(f0));
+        if (second) stg16(a.y, (r + stride) * a.y_ld8 + m.cg, pack8(f1));
     }
 }
 
@@ -275,6 +277,7 @@ struct BwdArgs {
     float inv_count;
     float* gw_sink; float* gb_sink;        // optional: += local Σdy'·x̂ / Σdy' (parameter-gradient arenas)
     const float* lsdy; const float* lsdyx; // local (pre all-reduce) sums feeding the sinks
+    long dy_ld8;    // dy row stride in 16-byte chunks (C/8, or the concat buffer's when dy is a slice of it)
     int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0, 3: as 2, and the fused
                     //    dropout's keep bit recomputed from the hash (dy' = keep·relu'·dy·scale)
     Drop drop;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(BwdArgs a) {
             const long q0 = r * C8 + m.cg;
             const bool second = r + stride < a.M;
             const long q1 = second ? (r + stride) * C8 + m.cg : q0;
-            uint4 d0 = ldg16(a.dy, q0), d1 = ldg16(a.dy, q1);
+            uint4 d0 = ldg16(a.dy, r * a.dy_ld8 + m.cg), d1 = ldg16(a.dy, (second ? r + stride : r) * a.dy_ld8 + m.cg);
             uint4 x0 = ldg16(a.x, q0), x1 = ldg16(a.x, q1);
             uint4 y0 = x0, y1 = x1;
             if (a.mask_mode == 1) { y0 = ldg16(a.y, q0); y1 = ldg16(a.y, q1); }
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
         const long q0 = r * C8 + m.cg;
         const bool second = r + stride < a.M;
         const long q1 = second ? (r + stride) * C8 + m.cg : q0;
-        uint4 d0 = ldg16(a.dy, q0), d1 = ldg16(a.dy, q1);
+        uint4 d0 = ldg16(a.dy, r * a.dy_ld8 + m.cg), d1 = ldg16(a.dy, (second ? r + stride : r) * a.dy_ld8 + m.cg);
         uint4 x0 = ldg16(a.x, q0), x1 = ldg16(a.x, q1);
         uint4 y0 = x0, y1 = x1;
         if (a.mask_mode == 1) { y0 = ldg16(a.y, q0); y1 = ldg16(a.y, q1); }
@@ -433,6 +436,15 @@ inline dim3 grid_reduce(long M, int C) {
 // set by dp_bn_set_dropout for the NEXT apply_stats / bwd_reduce / bwd_apply launch of this thread
 thread_local Drop t_drop = {0u, 1.f, 0u, 0u};
 
+// row strides (in elements) of the NEXT launch's y (apply) / dy (backward): set by dp_bn_set_ld, 0 = C
+thread_local long t_ld = 0;
+
+inline long take_ld8(int C) {
+    const long ld = t_ld > 0 ? t_ld : C;
+    t_ld = 0;
+    return ld / 8;
+}
+
 inline Drop take_drop() {
     const Drop d = t_drop;
     t_drop = Drop{0u, 1.f, 0u, 0u};
@@ -450,6 +462,14 @@ DP_EXPORT int dp_bn_stats(const void* x, long M, int C, float* sum, float* sq, h
     hipLaunchKernelGGL(bn_stats_kernel, grid_reduce(M, C), dim3(kThreads), 0, st,
                        (const bf16_raw*)x, M, C, sum, sq);
     return DP_LAUNCH_STATUS();
+}
+
+// ld: row stride in elements (>= C, multiple of 8) of the output of the next apply launch or of the dy of
+// the next backward launch of this thread — a channel slice of a wider NHWC buffer
+DP_EXPORT int dp_bn_set_ld(long ld) {
+    if (ld <= 0 || ld % 8 != 0) return -1;
+    t_ld = ld;
+    return 0;
 }
 
 // thr16: round(p * 65536) in [1, 65535]; consumed (and cleared) by the next launch listed above
@@ -475,6 +495,8 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
     a.unbias = count > 1.f ? count / (count - 1.f) : 1.f;
     a.relu = relu; a.nrep = nrep < 1 ? 1 : nrep; a.rep_stride = rep_stride;
     a.drop = take_drop();
+    a.y_ld8 = take_ld8(C);
+    if (a.y_ld8 * 8 < C || ((uintptr_t)y & 15)) return -1;
     hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
@@ -485,6 +507,8 @@ DP_EXPORT int dp_bn_apply_affine(const void* x, const void* res, void* y, long M
     ApplyArgs a{};
     a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
     a.scale = scale; a.shift = shift; a.relu = relu;
+    a.y_ld8 = take_ld8(C);
+    if (a.y_ld8 * 8 < C || ((uintptr_t)y & 15)) return -1;
     hipLaunchKernelGGL(bn_apply_kernel<false>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
@@ -498,7 +522,8 @@ DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, lon
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias;
     a.out_sdy = out_sdy; a.out_sdyx = out_sdyx; a.mask_mode = mask_mode;
     a.drop = take_drop();
-    if (mask_mode == 3 && a.drop.thr == 0) return -1;
+    a.dy_ld8 = take_ld8(C);
+    if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid_reduce(M, C), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
@@ -515,7 +540,8 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     a.inv_count = 1.f / count; a.mask_mode = mask_mode;
     a.gw_sink = gw_sink; a.gb_sink = gb_sink; a.lsdy = lsdy; a.lsdyx = lsdyx;
     a.drop = take_drop();
-    if (mask_mode == 3 && a.drop.thr == 0) return -1;
+    a.dy_ld8 = take_ld8(C);
+    if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
 }

@@ -132,6 +132,8 @@ __global__ __launch_bounds__(kCeThreads) void softmax_ce_bwd_kernel(const bf16_r
 struct Resize {
     int N, C, Hi, Wi, Ho, Wo;
     float ry, rx;  // input step per output pixel: (Hi-1)/(Ho-1)
+    int ldo;       // channel stride of the HIGH-resolution tensor (forward's y, backward's dy): C, or the
+                   // row width of the concat buffer it is a slice of
 };
 
 template <int VEC>
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const bf16_raw* __res
         const bf16_raw* p01 = base + ((long)y0 * p.Wi + x1) * p.C;
         const bf16_raw* p10 = base + ((long)y1 * p.Wi + x0) * p.C;
         const bf16_raw* p11 = base + ((long)y1 * p.Wi + x1) * p.C;
-        bf16_raw* dst = y + (((long)n * p.Ho + oy) * p.Wo + ox) * p.C + cv * VEC;
+        bf16_raw* dst = y + (((long)n * p.Ho + oy) * p.Wo + ox) * p.ldo + cv * VEC;
         if (VEC == 8) {
             float a[8], b[8], c[8], d[8], o[8];
             unpack8(*reinterpret_cast<const uint4*>(p00), a);
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const bf16_raw* __res
         float acc[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-        const bf16_raw* base = dy + (long)n * p.Ho * p.Wo * p.C + cv * VEC;
+        const bf16_raw* base = dy + (long)n * p.Ho * p.Wo * p.ldo + cv * VEC;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             // replicate the forward's tap selection exactly (including the clamped last row)
             const float sy = oy * p.ry;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const bf16_raw* __res
                 if (x1 == ix) wx += fx;
                 if (wx == 0.f) continue;
                 const float w = wy * wx;
-                const bf16_raw* src = base + ((long)oy * p.Wo + ox) * p.C;
+                const bf16_raw* src = base + ((long)oy * p.Wo + ox) * p.ldo;
                 if (VEC == 8) {
                     float f[8];
                     unpack8(*reinterpret_cast<const uint4*>(src), f);
@@ -276,9 +278,14 @@ DP_EXPORT int dp_softmax_ce_bwd(const void* logits, const void* target, int labe
     return DP_LAUNCH_STATUS();
 }
 
-DP_EXPORT int dp_bilinear_fwd(const void* x, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
-    if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return -1;
-    Resize p{N, C, Hi, Wi, Ho, Wo, Ho > 1 ? (float)(Hi - 1) / (Ho - 1) : 0.f, Wo > 1 ? (float)(Wi - 1) / (Wo - 1) : 0.f};
+// ldo: channel stride (elements) of the high-resolution tensor — C, or the row width of the concat buffer
+// that y (forward) / dy (backward) is a channel slice of
+DP_EXPORT int dp_bilinear_fwd_ld(const void* x, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo, int ldo,
+                                 hipStream_t st) {
+    if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || ldo < C) return -1;
+    if (C % 8 == 0 && (ldo % 8 != 0 || ((uintptr_t)y & 15))) return -1;
+    Resize p{N, C, Hi, Wi, Ho, Wo, Ho > 1 ? (float)(Hi - 1) / (Ho - 1) : 0.f, Wo > 1 ? (float)(Wi - 1) / (Wo - 1) : 0.f,
+             ldo};
     if (C % 8 == 0) {
         const long total = (long)N * Ho * Wo * (C / 8);
         hipLaunchKernelGGL(bilinear_fwd_kernel<8>, dim3(grid_1d(total, 256)), dim3(256), 0, st,
@@ -291,10 +298,16 @@ DP_EXPORT int dp_bilinear_fwd(const void* x, void* y, int N, int C, int Hi, int 
     return DP_LAUNCH_STATUS();
 }
 
-DP_EXPORT int dp_bilinear_bwd(const void* dy, void* dx, int N, int C, int Hi, int Wi, int Ho, int Wo,
-                              hipStream_t st) {
-    if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return -1;
-    Resize p{N, C, Hi, Wi, Ho, Wo, Ho > 1 ? (float)(Hi - 1) / (Ho - 1) : 0.f, Wo > 1 ? (float)(Wi - 1) / (Wo - 1) : 0.f};
+DP_EXPORT int dp_bilinear_fwd(const void* x, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
+    return dp_bilinear_fwd_ld(x, y, N, C, Hi, Wi, Ho, Wo, C, st);
+}
+
+DP_EXPORT int dp_bilinear_bwd_ld(const void* dy, void* dx, int N, int C, int Hi, int Wi, int Ho, int Wo, int ldo,
+                                 hipStream_t st) {
+    if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || ldo < C) return -1;
+    if (C % 8 == 0 && (ldo % 8 != 0 || ((uintptr_t)dy & 15))) return -1;
+    Resize p{N, C, Hi, Wi, Ho, Wo, Ho > 1 ? (float)(Hi - 1) / (Ho - 1) : 0.f, Wo > 1 ? (float)(Wi - 1) / (Wo - 1) : 0.f,
+             ldo};
     if (C % 8 == 0) {
         const long total = (long)N * Hi * Wi * (C / 8);
         hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid_1d(total, 256)), dim3(256), 0, st,
@@ -305,4 +318,9 @@ DP_EXPORT int dp_bilinear_bwd(const void* dy, void* dx, int N, int C, int Hi, in
                            (const bf16_raw*)dy, (bf16_raw*)dx, p);
     }
     return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_bilinear_bwd(const void* dy, void* dx, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                              hipStream_t st) {
+    return dp_bilinear_bwd_ld(dy, dx, N, C, Hi, Wi, Ho, Wo, C, st);
 }

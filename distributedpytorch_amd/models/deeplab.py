@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops import conv_bn_act, BatchNorm2d, Conv2d, GlobalAvgPool, bilinear_resize
+from ..ops.concat import ChannelConcat
 from .resnet import ResNet
 from .xception import AlignedXception
 
@@ -28,8 +29,8 @@ class _ASPPBranch(nn.Module):
         self.atrous_conv = Conv2d(cin, cout, k, padding=p, dilation=dilation, bias=False)
         self.bn = BatchNorm2d(cout)
 
-    def forward(self, x, passthrough: bool = False):
-        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True, passthrough=passthrough)
+    def forward(self, x, passthrough: bool = False, out=None):
+        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True, passthrough=passthrough, out=out)
 
 
 class _ImagePool(nn.Module):
@@ -64,13 +65,15 @@ class ASPP(nn.Module):
         # five consumers of x: thread it through the four convolutions' autograd nodes so their
         # data-gradient kernels accumulate dL/dx in the store loop (no 4 add kernels over the
         # 2048-channel map; see models.resnet._FanOutMixin)
-        b1, x = self.aspp1(x, passthrough=True)
-        b2, x = self.aspp2(x, passthrough=True)
-        b3, x = self.aspp3(x, passthrough=True)
-        b4, x = self.aspp4(x, passthrough=True)
-        pooled = self.global_avg_pool(x)
-        pooled = pooled.expand(-1, -1, h, w)  # align_corners bilinear of a 1×1 map = broadcast
-        y = torch.cat([b1, b2, b3, b4, pooled], dim=1)
+        # the branches write their channel slices of the concat buffer in place (ops.concat): no cat kernel
+        cout = self.conv1.in_channels // 5
+        cc = ChannelConcat(x, (cout,) * 5, (h, w))
+        b1, x = self.aspp1(x, passthrough=True, out=cc.slot(0))
+        b2, x = self.aspp2(x, passthrough=True, out=cc.slot(1))
+        b3, x = self.aspp3(x, passthrough=True, out=cc.slot(2))
+        b4, x = self.aspp4(x, passthrough=True, out=cc.slot(3))
+        pooled = cc.broadcast(4, self.global_avg_pool(x))   # align_corners bilinear of a 1×1 map = broadcast
+        y = cc.result(b1, b2, b3, b4, pooled)
         return conv_bn_act(self.conv1, self.bn1, y, relu=True, dropout=self.p_drop)
 
 
@@ -100,9 +103,13 @@ class Decoder(nn.Module):
         self.last_conv = _LastConv(256 + 48, num_classes)
 
     def forward(self, x, low):
-        low = conv_bn_act(self.conv1, self.bn1, low, relu=True)
-        x = bilinear_resize(x, low.shape[2:])
-        return self.last_conv(torch.cat([x, low], dim=1), self.training)
+        size = low.shape[2:]
+        cc = ChannelConcat(x, (x.shape[1], self.conv1.out_channels), size)
+        if tuple(x.shape[2:]) == tuple(size):
+            cc.in_place = False                       # nothing to resize: no producer to write slot 0
+        low = conv_bn_act(self.conv1, self.bn1, low, relu=True, out=cc.slot(1))
+        x = bilinear_resize(x, size, out=cc.slot(0))
+        return self.last_conv(cc.result(x, low), self.training)
 
 
 class DeepLabV3Plus(nn.Module):

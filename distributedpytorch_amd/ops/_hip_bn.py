@@ -26,6 +26,7 @@ def _lib():
             [c_int, c_void_p]
         lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int] + \
             [c_void_p] * 5
+        lib.dp_bn_set_ld.argtypes = [c_long]
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         _sigs_done = True
     return lib
@@ -40,6 +41,37 @@ def _check_act(t: torch.Tensor, name: str, like: torch.Tensor | None = None):
         raise ValueError(f"{name}: channel count {t.shape[1]} must be a multiple of 8")
     if like is not None and t.shape != like.shape:
         raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(like.shape)}")
+
+
+def _strided(t: torch.Tensor, name: str, like: torch.Tensor):
+    """(tensor, ld): ``t`` as NHWC rows of ld >= C elements — kept as is when it is a channel slice of a
+    wider channels-last buffer (ops.concat), made channels-last contiguous otherwise."""
+    from .concat import row_stride
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name}: HIP BatchNorm path needs bf16 activations, got {t.dtype}")
+    if t.shape != like.shape:
+        raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(like.shape)}")
+    ld = row_stride(t)
+    if ld is None or ld % 8 != 0 or t.data_ptr() % 16 != 0:
+        t = as_nhwc(t)
+        ld = t.shape[1]
+    return t, ld
+
+
+def _arm_ld(ld: int, C: int) -> None:
+    if ld != C:
+        B.check(_lib().dp_bn_set_ld(int(ld)), "bn_set_ld")
+
+
+def _out_slice(out, x):
+    """The slot view a producer writes (ops.concat.Slot) and its row stride."""
+    buf, off, c = out
+    n, C, h, w = x.shape
+    if (c != C or buf.dtype != x.dtype or buf.device != x.device or buf.shape[0] != n
+            or tuple(buf.shape[2:]) != (h, w) or not buf.is_contiguous(memory_format=torch.channels_last)
+            or off % 8 != 0 or buf.shape[1] % 8 != 0 or off + c > buf.shape[1]):
+        raise ValueError("out: concat slot does not match the activation")
+    return buf[:, off:off + c], buf.shape[1]
 
 
 def _check_vec(t: torch.Tensor | None, C: int, name: str):
@@ -67,7 +99,7 @@ def stats(x: torch.Tensor):
     return buf[0], buf[1]
 
 
-def apply(x, scale, shift, residual, relu):
+def apply(x, scale, shift, residual, relu, out=None):
     """Affine form (eval / frozen statistics)."""
     x = as_nhwc(x)
     _check_act(x, "x")
@@ -77,7 +109,11 @@ def apply(x, scale, shift, residual, relu):
     if residual is not None:
         residual = as_nhwc(residual)
         _check_act(residual, "residual", x)
-    y = torch.empty_like(x)
+    if out is not None:
+        y, ld = _out_slice(out, x)
+        _arm_ld(ld, C)
+    else:
+        y = torch.empty_like(x)
     B.check(_lib().dp_bn_apply_affine(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(scale), B.ptr(shift),
                                       int(relu), B.stream_ptr()), "bn_apply_affine")
     return y
@@ -91,7 +127,7 @@ def _arm_dropout(dropout) -> None:
 
 
 def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var, count, eps, momentum, relu,
-                     replicas=None, dropout=None):
+                     replicas=None, dropout=None, out=None):
     """Training form: finalises mean/invstd/running stats inside the apply kernel.
     ``replicas``: optional fp32 [R, 2, C] partial statistics from the conv epilogue (then ``s``/``ss``
     are ignored and the kernel sums the R replicas itself).  Returns (y, mean, invstd)."""
@@ -111,9 +147,14 @@ def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var
     if residual is not None:
         residual = as_nhwc(residual)
         _check_act(residual, "residual", x)
-    y = torch.empty_like(x)
+    ld = C
+    if out is not None:
+        y, ld = _out_slice(out, x)
+    else:
+        y = torch.empty_like(x)
     mi = torch.empty(2, C, dtype=torch.float32, device=x.device)
     _arm_dropout(dropout)
+    _arm_ld(ld, C)
     B.check(_lib().dp_bn_apply_stats(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(s), B.ptr(ss),
                                      B.ptr(weight), B.ptr(bias), B.ptr(mi[0]), B.ptr(mi[1]),
                                      B.ptr(running_mean), B.ptr(running_var), float(count), float(eps),
@@ -123,8 +164,8 @@ def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var
 
 
 def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode, dropout=None):
-    dy = as_nhwc(dy)
-    _check_act(x, "x"); _check_act(dy, "dy", x)
+    _check_act(x, "x")
+    dy, ld = _strided(dy, "dy", x)
     M, C = _mc(x)
     if mask_mode == 1:
         _check_act(y, "y", x)
@@ -134,6 +175,7 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode, dropout=None):
     if (mask_mode == 3) != (dropout is not None):
         raise ValueError("mask_mode 3 <=> fused dropout")
     _arm_dropout(dropout)
+    _arm_ld(ld, C)
     B.check(_lib().dp_bn_bwd_reduce(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), M, C,
                                     B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                     B.ptr(buf[0]), B.ptr(buf[1]), int(mask_mode), B.stream_ptr()), "bn_bwd_reduce")
@@ -142,8 +184,8 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode, dropout=None):
 
 def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres,
               gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None, dropout=None):
-    dy = as_nhwc(dy)
-    _check_act(x, "x"); _check_act(dy, "dy", x)
+    _check_act(x, "x")
+    dy, ld = _strided(dy, "dy", x)
     M, C = _mc(x)
     if mask_mode == 1:
         _check_act(y, "y", x)
@@ -158,6 +200,7 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
     if (mask_mode == 3) != (dropout is not None):
         raise ValueError("mask_mode 3 <=> fused dropout")
     _arm_dropout(dropout)
+    _arm_ld(ld, C)
     B.check(_lib().dp_bn_bwd_apply(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), B.ptr(dx),
                                    B.ptr(dres), M, C, B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                    B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.ptr(gw_sink),

@@ -32,6 +32,8 @@ def _lib():
         lib.dp_affine_augment.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V, V, V]
         lib.dp_confusion.argtypes = [V, I, V, I, L, I, I, I, V, V]
         lib.dp_pad_channels.argtypes = [V, V, L, I, I, V]
+        lib.dp_bilinear_fwd_ld.argtypes = [V, V, I, I, I, I, I, I, I, V]
+        lib.dp_bilinear_bwd_ld.argtypes = [V, V, I, I, I, I, I, I, I, V]
         lib.dp_stem_pack.argtypes = [V, V, L, I, I, I, I, V]
         _sigs_done = True
     return lib
@@ -125,21 +127,33 @@ def upsample_ce_bwd(x, ld, target, ignore_index, sums, gloss):
 
 
 # ------------------------------------------------------------------ bilinear
-def bilinear_fwd(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+def bilinear_fwd(x: torch.Tensor, size: Tuple[int, int], out=None) -> torch.Tensor:
     x = _req_bf16_nhwc(x, "x")
     n, c, hi, wi = x.shape
     ho, wo = size
-    y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    B.check(_lib().dp_bilinear_fwd(B.ptr(x), B.ptr(y), n, c, hi, wi, ho, wo, B.stream_ptr()), "bilinear_fwd")
+    ldo = c
+    if out is not None:
+        buf, off, cs = out                       # ops.concat slot: write the channel slice in place
+        if (cs != c or buf.dtype != x.dtype or tuple(buf.shape[2:]) != (ho, wo) or buf.shape[0] != n
+                or not buf.is_contiguous(memory_format=torch.channels_last) or off % 8 or c % 8 or buf.shape[1] % 8):
+            raise ValueError("bilinear_fwd: concat slot does not match the output")
+        y, ldo = buf[:, off:off + c], buf.shape[1]
+    else:
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    B.check(_lib().dp_bilinear_fwd_ld(B.ptr(x), B.ptr(y), n, c, hi, wi, ho, wo, ldo, B.stream_ptr()), "bilinear_fwd")
     return y
 
 
 def bilinear_bwd(dy: torch.Tensor, in_size: Tuple[int, int]) -> torch.Tensor:
-    dy = _req_bf16_nhwc(dy, "dy")
+    from .concat import row_stride
+    ld = row_stride(dy) if dy.dtype == torch.bfloat16 else None
+    if ld is None or ld % 8 or dy.data_ptr() % 16 or dy.shape[1] % 8:
+        dy = _req_bf16_nhwc(dy, "dy")
+        ld = dy.shape[1]
     n, c, ho, wo = dy.shape
     hi, wi = in_size
     dx = torch.empty((n, c, hi, wi), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
-    B.check(_lib().dp_bilinear_bwd(B.ptr(dy), B.ptr(dx), n, c, hi, wi, ho, wo, B.stream_ptr()), "bilinear_bwd")
+    B.check(_lib().dp_bilinear_bwd_ld(B.ptr(dy), B.ptr(dx), n, c, hi, wi, ho, wo, ld, B.stream_ptr()), "bilinear_bwd")
     return dx
 
 

@@ -66,10 +66,10 @@ def _t_bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, rel
     return dx.to(x.dtype), dres
 
 
-def _apply_affine(x, scale, shift, residual, relu):
+def _apply_affine(x, scale, shift, residual, relu, out=None):
     if B.use_hip(x):
         from . import _hip_bn
-        return _hip_bn.apply(x, scale, shift, residual, relu)
+        return _hip_bn.apply(x, scale, shift, residual, relu, out)
     return _t_apply(x, scale, shift, residual, relu)
 
 
@@ -99,8 +99,9 @@ def _group_active(group) -> bool:
 class _BatchNormActTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, group,
-                conv_stats=None, holder=None, dropout=None):
-        """``dropout`` = (thr16, seed) or None: dropout fused behind the ReLU (HIP path, no residual)."""
+                conv_stats=None, holder=None, dropout=None, out=None):
+        """``dropout`` = (thr16, seed) or None: dropout fused behind the ReLU (HIP path, no residual).
+        ``out``: an ops.concat slot — the result is written into that channel slice (HIP path)."""
         C = x.shape[1]
         local_count = x.numel() // C
         hip = B.use_hip(x)
@@ -146,7 +147,7 @@ class _BatchNormActTrain(torch.autograd.Function):
             w = weight.detach().float().contiguous() if weight is not None else None
             b = bias.detach().float().contiguous() if bias is not None else None
             y, mean, invstd = _hip_bn.apply_from_stats(x, s, ss, w, b, residual, running_mean, running_var,
-                                                       count, eps, momentum, relu, replicas, dropout)
+                                                       count, eps, momentum, relu, replicas, dropout, out)
             mask_mode = 0 if not relu else (1 if residual is not None else 2)
             if dropout is not None:
                 assert relu and residual is None
@@ -232,7 +233,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                     notify = getattr(prm, "_dpamd_on_grad", None)
                     if notify is not None:
                         notify(prm)
-                return dx, None, None, dres, None, None, None, None, None, None, None, None, None
+                return dx, None, None, dres, None, None, None, None, None, None, None, None, None, None
             from . import _hip_bn
             dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
                                          mask_mode, need_dres, dropout=ctx.dropout)
@@ -244,15 +245,15 @@ class _BatchNormActTrain(torch.autograd.Function):
         # clone: the sums may live in the per-step scratch pool, autograd may keep the tensor as .grad
         dweight = sdyx.to(ctx.wdtype, copy=True) if ctx.has_affine else None
         dbias = sdy.to(ctx.wdtype, copy=True) if ctx.has_affine else None
-        return dx, dweight, dbias, dres, None, None, None, None, None, None, None, None, None
+        return dx, dweight, dbias, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class _BatchNormActFrozen(torch.autograd.Function):
     """Eval-statistics BN (``freeze_bn``) fused with residual/ReLU; differentiable w.r.t. x."""
 
     @staticmethod
-    def forward(ctx, x, scale, shift, residual, relu):
-        y = _apply_affine(x, scale, shift, residual, relu)
+    def forward(ctx, x, scale, shift, residual, relu, out=None):
+        y = _apply_affine(x, scale, shift, residual, relu, out)
         ctx.save_for_backward(y if relu else None, scale)
         ctx.relu, ctx.has_res = relu, residual is not None
         return y
@@ -269,13 +270,13 @@ class _BatchNormActFrozen(torch.autograd.Function):
             ref = y if y is not None else _hip_bn.as_nhwc(dy)
             dx, dres = _hip_bn.bwd_apply(dy, ref, y, zeros, ones, scale.contiguous(), zeros, None, None, 1.0,
                                          1 if ctx.relu else 0, need_dres)
-            return dx, None, None, dres, None
+            return dx, None, None, dres, None, None
         dyf = dy.float()
         if ctx.relu:
             dyf = dyf * (y > 0)
         dx = (dyf * scale.view(1, -1, 1, 1)).to(dy.dtype)
         dres = dyf.to(dy.dtype) if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dx, None, None, dres, None
+        return dx, None, None, dres, None, None
 
 
 _drop_calls = 0
@@ -296,7 +297,7 @@ def _dropout_key(p: float):
 def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, training: bool,
                    momentum: float = 0.1, eps: float = 1e-5, relu: bool = False,
                    residual: Optional[torch.Tensor] = None, group=False,
-                   conv_stats: Optional[torch.Tensor] = None, dropout: float = 0.0) -> torch.Tensor:
+                   conv_stats: Optional[torch.Tensor] = None, dropout: float = 0.0, out=None) -> torch.Tensor:
     """``drop(act(BN(x) + residual))``.  ``group``: ``False`` = local statistics, ``True`` = default
     process group, or a ``ProcessGroup`` = statistics all-reduced over that group.  ``dropout``: the
     probability of an ``F.dropout`` behind the activation; on the HIP training path (ReLU, no residual)
@@ -307,13 +308,14 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
         if residual is not None:
             y = y + residual
         y = F.relu(y) if relu else y
-        return F.dropout(y, dropout, True) if dropout > 0.0 else y
+        return F.dropout(y, dropout, training) if dropout > 0.0 else y
     if training:
         holder = {} if (relu and B.use_hip(x)) else None
         fuse_drop = dropout > 0.0 and relu and residual is None and B.use_hip(x) and _FUSE_DROPOUT
         y = _BatchNormActTrain.apply(x, weight, bias, residual, running_mean, running_var,
                                      momentum, eps, relu, group, conv_stats, holder,
-                                     _dropout_key(dropout) if fuse_drop else None)
+                                     _dropout_key(dropout) if fuse_drop else None,
+                                     out if B.use_hip(x) else None)
         if dropout > 0.0 and not fuse_drop:
             return F.dropout(y, dropout, True)
         if holder and not fuse_drop:
@@ -325,8 +327,9 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
     scale = invstd * (weight.float() if weight is not None else 1.0)
     shift = (bias.float() if bias is not None else 0.0) - running_mean.float() * scale
     if torch.is_grad_enabled() and x.requires_grad:
-        return _BatchNormActFrozen.apply(x, scale, shift, residual, relu)
-    return _apply_affine(x, scale, shift, residual, relu)
+        # (its backward reads the saved output as the ReLU mask source, contiguously: no concat slot)
+        return _BatchNormActFrozen.apply(x, scale, shift, residual, relu, None)
+    return _apply_affine(x, scale, shift, residual, relu, out)
 
 
 class BatchNorm2d(nn.Module):
@@ -348,18 +351,20 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                stats: Optional[torch.Tensor] = None, dropout: float = 0.0):
+                stats: Optional[torch.Tensor] = None, dropout: float = 0.0, out=None):
         """``dropout``: probability of a dropout behind the activation, applied in training mode only
         (fused into the BN kernels on the HIP path)."""
         training = self.training and not self.frozen
         if dropout > 0.0 and not training:
-            y = self.forward(x, relu, residual, stats)
-            return F.dropout(y, dropout, self.training)
+            if not self.training:
+                dropout = 0.0                       # eval: identity, and the result may go to `out`
+            else:                                   # frozen statistics in training mode: separate dropout
+                return F.dropout(self.forward(x, relu, residual, stats), dropout, True)
         group = False
         if self.sync and training:
             group = self.process_group if self.process_group is not None else True
         return batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                              training, self.momentum, self.eps, relu, residual, group, stats, dropout)
+                              training, self.momentum, self.eps, relu, residual, group, stats, dropout, out)
 
     def extra_repr(self) -> str:
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "

@@ -139,28 +139,32 @@ class Conv2d(nn.Module):
 
 def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
                 residual: Optional[torch.Tensor] = None, passthrough: bool = False, sole_consumer: bool = False,
-                dropout: float = 0.0):
+                dropout: float = 0.0, out=None):
     """``act(BN(conv(x)) + residual)``.  On the GPU path the batch statistics come out of the conv
     kernel's epilogue (no separate statistics pass over the activation).
 
     ``dropout``: probability of a dropout behind the activation (training only), run inside the BN
     kernels on the GPU path (ops.batchnorm).
 
+    ``out``: an ``ops.concat`` slot — the result is written straight into that channel slice of a concat
+    buffer (GPU path; ignored elsewhere, ``ChannelConcat.result`` then falls back to ``torch.cat``).
+
     ``passthrough=True`` returns ``(out, x')`` where ``x'`` is ``x`` routed through the convolution's
     autograd node: use ``x'`` as the block's identity and the skip-path gradient is added inside the
     data-gradient kernel (csrc/conv_igemm2.hip store loop) instead of by an add kernel."""
+    slot = out
     pt = passthrough and conv.can_passthrough(x)
     if bn.training and not bn.frozen and conv.can_fuse_stats(x):
         if pt:
             y, stats, skip = conv(x, with_stats=True, passthrough=True, sole_consumer=sole_consumer)
         else:
             y, stats = conv(x, with_stats=True, sole_consumer=sole_consumer)
-        out = bn(y, relu=relu, residual=residual, stats=stats, dropout=dropout)
+        out = bn(y, relu=relu, residual=residual, stats=stats, dropout=dropout, out=slot)
     elif pt:
         y, skip = conv(x, passthrough=True, sole_consumer=sole_consumer)
-        out = bn(y, relu=relu, residual=residual, dropout=dropout)
+        out = bn(y, relu=relu, residual=residual, dropout=dropout, out=slot)
     else:
-        out = bn(conv(x, sole_consumer=sole_consumer), relu=relu, residual=residual, dropout=dropout)
+        out = bn(conv(x, sole_consumer=sole_consumer), relu=relu, residual=residual, dropout=dropout, out=slot)
     if passthrough:
         return out, (skip if pt else x)
     return out

@@ -18,23 +18,24 @@ from . import _backend as B
 
 class _BilinearHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, size):
+    def forward(ctx, x, size, out=None):
         from . import _hip_misc
         ctx.in_size = (x.shape[2], x.shape[3])
-        return _hip_misc.bilinear_fwd(x, size)
+        return _hip_misc.bilinear_fwd(x, size, out)
 
     @staticmethod
     def backward(ctx, dy):
         from . import _hip_misc
-        return _hip_misc.bilinear_bwd(dy, ctx.in_size), None
+        return _hip_misc.bilinear_bwd(dy, ctx.in_size), None, None
 
 
-def bilinear_resize(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+def bilinear_resize(x: torch.Tensor, size: Tuple[int, int], out=None) -> torch.Tensor:
+    """``out``: an ``ops.concat`` slot to write the result into (GPU path; ignored elsewhere)."""
     size = (int(size[0]), int(size[1]))
     if tuple(x.shape[2:]) == size:
         return x
     if B.use_hip(x):
-        return _BilinearHip.apply(x, size)
+        return _BilinearHip.apply(x, size, out)
     return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
 

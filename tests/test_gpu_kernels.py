@@ -628,3 +628,40 @@ def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name):
     assert worst < max(6e-2, 8 * noise), (worst, noise)
 
 
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_inplace_concat_matches_torch_cat(train):
+    """ops.concat: ASPP + decoder with every producer writing its channel slice of the concat buffer
+    (BN output row stride, bilinear output stride, broadcast) and every backward consumer reading its
+    slice of the concat gradient through the stride — against the same modules run with torch.cat."""
+    from distributedpytorch_amd.models.deeplab import ASPP, Decoder
+    from distributedpytorch_amd.ops import batchnorm as bn_mod
+    from distributedpytorch_amd.ops import concat
+
+    def run(flag):
+        old = concat.ENABLED
+        concat.ENABLED = flag
+        try:
+            torch.manual_seed(21)
+            bn_mod._drop_calls = 0                       # same fused-dropout seeds in both runs
+            aspp, dec = ASPP(64, 16).to(DEV), Decoder(32, 21).to(DEV)
+            for m in (aspp, dec):
+                m.to(memory_format=torch.channels_last).train(train)
+            feat = _nhwc(_bf(torch.randn(2, 64, 9, 11, device=DEV))).requires_grad_(True)
+            low = _nhwc(_bf(torch.randn(2, 32, 33, 41, device=DEV))).requires_grad_(True)
+            out = dec(aspp(feat), low)
+            out.float().pow(2).mean().backward()
+            g = {f"aspp.{n}": p.grad.float().clone() for n, p in aspp.named_parameters() if p.grad is not None}
+            g.update({f"dec.{n}": p.grad.float().clone() for n, p in dec.named_parameters() if p.grad is not None})
+            g["feat"], g["low"] = feat.grad.float().clone(), low.grad.float().clone()
+            return out.detach().float(), g
+        finally:
+            concat.ENABLED = old
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    o00, g00 = run(False)
+    assert _rel(o1, o0) < 2e-2
+    worst = max(_rel(g1[k], g0[k]) for k in g0)
+    noise = max(_rel(g00[k], g0[k]) for k in g0)        # atomics order of the fused statistics
+    assert worst < max(3e-2, 6 * noise), (worst, noise)
