@@ -111,7 +111,9 @@ def main():
             if on_gpu:
                 print(f"[bench] peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
         rec = {
-            "metric": "train images/sec (node) DeepLabv3+ R101 513x513",
+            "metric": ("train images/sec (node) DeepLabv3+ R101 513x513"
+                   if (args.model == "deeplabv3plus_resnet101" and args.crop == 513)
+                   else f"train images/sec (node) {args.model} {args.crop}x{args.crop}"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -302,11 +302,201 @@ __global__ __launch_bounds__(256) void dwconv2_bwd_weight_kernel(const bf16_raw*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third generation: LDS row tiles (stride 1, "same" padding: pad == dil — every Xception middle/exit
+// unit).  Both mappings above leave the 9x reuse of an input element to the caches: with dilation d the
+// three tap rows of a pixel are 2d image rows apart (d = 2, 728 channels, 65 columns: 376 KB), far beyond
+// L1, so every tap is an L2 request — 8 TB/s of L2 traffic for a 100 MB tensor, 2.5x (fwd) to 8x (wgrad)
+// off the HBM time (profiles/r1_native_x65_os8_b16_v2.md).  Here a block stages TH + 2d FULL-WIDTH image
+// rows x 64 channels in LDS once (global reads: (TH + 2d) / TH of the tensor, 128 contiguous bytes per
+// pixel), and all taps are conflict-free ds_read_b128: a wave reads 8 neighbouring pixels x 8 channel
+// groups = 1 KiB contiguous.
+//   MODE 0: out = depthwise conv of `in` (forward; data gradient = the same with the taps flipped)
+//   MODE 2: dw[t][c] += sum over the tile of in2 (dy) x tap t of `in` (x): 72 partial sums per thread,
+//           block combine through the (by then free) LDS tile, one atomic per (tap, channel) and block.
+struct Dw3 {
+    const bf16_raw* in; const bf16_raw* in2; const bf16_raw* w9; void* out;
+    int N, C, H, W, dil, TH, tiles_h, flip;
+    unsigned in_bytes;
+};
+
+constexpr unsigned kOOBd = 0x80000000u;
+constexpr int kDw3MaxPx = 12;          // MODE 2: pixels per thread whose dy is pre-loaded into registers
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const uint4* tile = reinterpret_cast<const uint4*>(smem3);      // [rows + 2d][W][8] 16-byte chunks
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.y * 64;
+    const int ncg = min(8, (p.C - c0) >> 3);
+    const int n = blockIdx.x / p.tiles_h, th = blockIdx.x - n * p.tiles_h;
+    const int y0 = th * p.TH;
+    const int rows = min(p.TH, p.H - y0);
+    const int d = p.dil;
+    const int R = rows + 2 * d;
+    const int cg = tid & 7, pl = tid >> 3;
+    const bool cg_ok = cg < ncg;
+    const int npix = rows * p.W;
+
+    // MODE 2: this thread's dy vectors go to registers first — their latency hides under the staging
+    uint4 dq[kDw3MaxPx];
+    if (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < kDw3MaxPx; ++k) {
+            const int pi = pl + 32 * k;
+            dq[k] = make_uint4(0, 0, 0, 0);
+            if (cg_ok && pi < npix)
+                dq[k] = *reinterpret_cast<const uint4*>(p.in2 + ((long)n * p.H * p.W + (long)y0 * p.W + pi) * p.C + c0 + cg * 8);
+        }
+    }
+    // ---- stage through LDS-DMA: one wave-instruction = 8 pixels x 128 bytes = 1 KiB, linear in LDS.
+    // Rows outside the image, channel groups beyond C and the tail pixels get an out-of-range offset:
+    // the buffer range check writes zeros.
+    {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+        const int c8 = lane & 7;
+        const int npx = R * p.W;
+        const unsigned img = (unsigned)(((long)n * p.H * p.W * p.C + c0 + c8 * 8) * 2);
+        for (int q0 = wave * 8; q0 < npx; q0 += 32) {
+            const int q = q0 + (lane >> 3);
+            const int r = q / p.W, px = q - r * p.W;
+            const int iy = y0 - d + r;
+            const bool ok = (c8 < ncg) & (q < npx) & ((unsigned)iy < (unsigned)p.H);
+            const unsigned off = img + (unsigned)((iy * p.W + px) * p.C * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem3 + q0 * 128), 16,
+                                                     ok ? off : kOOBd, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (MODE == 0) {
+        float w[9][8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (cg_ok) unpack8(*reinterpret_cast<const uint4*>(p.w9 + (p.flip ? 8 - t : t) * p.C + c0 + cg * 8), w[t]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[t][j] = 0.f;
+            }
+        }
+        bf16_raw* out = reinterpret_cast<bf16_raw*>(p.out);
+        for (int pi = pl; pi < npix; pi += 32) {
+            const int y = pi / p.W, x = pi - y * p.W;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int ix = x - d + q * d;
+                    if ((unsigned)ix >= (unsigned)p.W) continue;
+                    float xv[8];
+                    unpack8(tile[((y + a * d) * p.W + ix) * 8 + cg], xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[a * 3 + q][j], acc[j]);
+                }
+            }
+            if (cg_ok)
+                *reinterpret_cast<uint4*>(out + (((long)n * p.H + y0 + y) * p.W + x) * p.C + c0 + cg * 8) = pack8(acc);
+        }
+    } else {
+        float acc[9][8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < kDw3MaxPx; ++k) {
+            const int pi = pl + 32 * k;
+            if (pi < npix) {
+                const int y = pi / p.W, x = pi - y * p.W;
+                float dv[8];
+                unpack8(dq[k], dv);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int ix = x - d + q * d;
+                        if ((unsigned)ix >= (unsigned)p.W) continue;
+                        float xv[8];
+                        unpack8(tile[((y + a * d) * p.W + ix) * 8 + cg], xv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[a * 3 + q][j] = fmaf(dv[j], xv[j], acc[a * 3 + q][j]);
+                    }
+                }
+            }
+        }
+        // ---- block combine: red[pixel lane][cg][72] over the tile's LDS (the launch allocates >= 73,728 B)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem3);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(pl * 8 + cg) * 72 + t * 8 + j] = acc[t][j];
+        __syncthreads();
+        float* dw = reinterpret_cast<float*>(p.out);
+        for (int o = tid; o < 8 * 72; o += 256) {
+            const int g = o / 72, e = o - g * 72;
+            if (g >= ncg) continue;
+            float v = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 72 + e];
+            const int t = e >> 3, j = e & 7;
+            atomicAdd(dw + t * p.C + c0 + g * 8 + j, v);
+        }
+    }
+}
+
+// rows per tile, 0 = shape not taken (then the older kernels run).  Two blocks per CU when the tile fits
+// in 80 KiB (one block stages while the other computes), else one block of up to 150 KiB.
+inline int dw3_rows(int H, int W, int dil, bool wgrad) {
+    const long row_bytes = (long)W * 128;
+    long th = (80 * 1024) / row_bytes - 2 * dil;
+    if (th < 1 || th < dil) th = (150 * 1024) / row_bytes - 2 * dil;
+    if (th > H) th = H;
+    if (wgrad && th * W > 32 * kDw3MaxPx) th = (32 * kDw3MaxPx) / W;
+    if (th < 1) return 0;
+    return (int)th;
+}
+
+template <int MODE>
+inline int launch_dw3(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
+                      int flip, int TH, hipStream_t st) {
+    const long in_bytes = (long)N * H * W * C * 2;
+    if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
+    Dw3 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TH, (H + TH - 1) / TH, flip,
+          (unsigned)in_bytes};
+    const long nb = (long)N * p.tiles_h;
+    if (nb > 0x7fffffffL) return -4;
+    int lds = (TH + 2 * dil) * W * 128 + 1024;                  // + one wave-instruction of slack for the tail
+    if (MODE == 2 && lds < 32 * 8 * 72 * 4) lds = 32 * 8 * 72 * 4;
+    if (lds > 160 * 1024) return -2;
+    auto kfn = dwconv3_kernel<MODE>;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nb, (unsigned)((C + 63) / 64)), dim3(256), lds, st, p);
+    return DP_LAUNCH_STATUS();
+}
+
+static const int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 3;
+
 }  // namespace
 
 DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
                             int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
+    if (kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        const int th = dw3_rows(Hi, Wi, dil, false);
+        if (th > 0) {
+            const int rc = launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st);
+            if (rc != -2) return rc;
+        }
+    }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
     // strip mapping measured SLOWER here than the flat mapping (176 vs 111 us on the 728-channel 65x65
     // layers: a wave's loads split into two 512-B runs and a thread walks 8 pixels serially); it pays
@@ -327,6 +517,13 @@ DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C
 DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N, int C, int Hi, int Wi, int Ho,
                                  int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
+    if (kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        const int th = dw3_rows(Hi, Wi, dil, false);                 // = forward over dy with the taps flipped
+        if (th > 0) {
+            const int rc = launch_dw3<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, th, st);
+            if (rc != -2) return rc;
+        }
+    }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
     static const bool gen2 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 2;   // see dp_dwconv_fwd
     const long Pin = (long)N * Hi * Wi;
@@ -344,6 +541,13 @@ DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N
 DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int N, int C, int Hi, int Wi, int Ho,
                                    int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
+    if (kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        const int th = dw3_rows(Hi, Wi, dil, true);
+        if (th > 0) {
+            const int rc = launch_dw3<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, th, st);
+            if (rc != -2) return rc;
+        }
+    }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
     const int C8 = C / 8;
     static const bool gen1 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 1;

@@ -207,9 +207,12 @@ def test_wgrad_splits(case, splits):
 
 
 @pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
-def test_depthwise(stride, dil):
+@pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (1, 64, 7, 129)])
+def test_depthwise(stride, dil, shape):
+    """flat kernels (stride 2) and the LDS row-tiled kernels (stride 1, several tiles per image,
+    partial 64-channel slab) against an fp32 CPU grouped convolution."""
     torch.manual_seed(1)
-    n, c, h, w = 2, 72, 33, 31
+    n, c, h, w = shape
     x = _bf(torch.randn(n, c, h, w, device=DEV))
     wt = _bf(torch.randn(c, 1, 3, 3, device=DEV) / 3)
     xr, wr = x.float().cpu().requires_grad_(True), wt.float().cpu().requires_grad_(True)
