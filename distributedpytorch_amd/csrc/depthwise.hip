@@ -326,7 +326,9 @@ constexpr int kDw3MaxPx = 12;          // MODE 2: pixels per thread whose dy is 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const uint4* tile = reinterpret_cast<const uint4*>(smem3);      // [rows + 2d][W][8] 16-byte chunks
+    // [rows + 2d][W + 2d][8] 16-byte chunks: the horizontal padding is physically present (zeros), so the
+    // nine taps of a pixel are nine FIXED offsets from its own chunk — no bounds tests in the tap loop
+    const uint4* tile = reinterpret_cast<const uint4*>(smem3);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
     const int rows = min(p.TH, p.H - y0);
     const int d = p.dil;
     const int R = rows + 2 * d;
+    const int Wt = p.W + 2 * d;
     const int cg = tid & 7, pl = tid >> 3;
     const bool cg_ok = cg < ncg;
     const int npix = rows * p.W;
@@ -359,13 +362,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
         const int c8 = lane & 7;
-        const int npx = R * p.W;
+        const int npx = R * Wt;
         const unsigned img = (unsigned)(((long)n * p.H * p.W * p.C + c0 + c8 * 8) * 2);
         for (int q0 = wave * 8; q0 < npx; q0 += 32) {
             const int q = q0 + (lane >> 3);
-            const int r = q / p.W, px = q - r * p.W;
+            const int r = q / Wt, px = q - r * Wt - d;
             const int iy = y0 - d + r;
-            const bool ok = (c8 < ncg) & (q < npx) & ((unsigned)iy < (unsigned)p.H);
+            const bool ok = (c8 < ncg) & (q < npx) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W);
             const unsigned off = img + (unsigned)((iy * p.W + px) * p.C * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem3 + q0 * 128), 16,
                                                      ok ? off : kOOBd, 0, 0, 0);
@@ -383,26 +386,28 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
                 for (int j = 0; j < 8; ++j) w[t][j] = 0.f;
             }
         }
-        bf16_raw* out = reinterpret_cast<bf16_raw*>(p.out);
+        bf16_raw* out = reinterpret_cast<bf16_raw*>(p.out) + ((long)n * p.H + y0) * p.W * p.C + c0 + cg * 8;
+        int toff[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) toff[a * 3 + q] = (a * d * Wt + q * d) * 8;
+        int y = pl / p.W, x = pl - y * p.W;             // pl < 32: at most a few rows down
         for (int pi = pl; pi < npix; pi += 32) {
-            const int y = pi / p.W, x = pi - y * p.W;
+            const uint4* t0 = tile + (y * Wt + x) * 8 + cg;
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
+            for (int t = 0; t < 9; ++t) {
+                float xv[8];
+                unpack8(t0[toff[t]], xv);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int ix = x - d + q * d;
-                    if ((unsigned)ix >= (unsigned)p.W) continue;
-                    float xv[8];
-                    unpack8(tile[((y + a * d) * p.W + ix) * 8 + cg], xv);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[a * 3 + q][j], acc[j]);
-                }
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[t][j], acc[j]);
             }
-            if (cg_ok)
-                *reinterpret_cast<uint4*>(out + (((long)n * p.H + y0 + y) * p.W + x) * p.C + c0 + cg * 8) = pack8(acc);
+            if (cg_ok) *reinterpret_cast<uint4*>(out + (long)pi * p.C) = pack8(acc);
+            x += 32;
+            while (x >= p.W) { x -= p.W; ++y; }
         }
     } else {
         float acc[9][8];
@@ -410,26 +415,29 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+        int toff[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) toff[a * 3 + q] = (a * d * Wt + q * d) * 8;
+        int y = pl / p.W, x = pl - y * p.W;
 #pragma unroll
         for (int k = 0; k < kDw3MaxPx; ++k) {
             const int pi = pl + 32 * k;
             if (pi < npix) {
-                const int y = pi / p.W, x = pi - y * p.W;
+                const uint4* t0 = tile + (y * Wt + x) * 8 + cg;
                 float dv[8];
                 unpack8(dq[k], dv);
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
+                for (int t = 0; t < 9; ++t) {
+                    float xv[8];
+                    unpack8(t0[toff[t]], xv);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int ix = x - d + q * d;
-                        if ((unsigned)ix >= (unsigned)p.W) continue;
-                        float xv[8];
-                        unpack8(tile[((y + a * d) * p.W + ix) * 8 + cg], xv);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[a * 3 + q][j] = fmaf(dv[j], xv[j], acc[a * 3 + q][j]);
-                    }
+                    for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(dv[j], xv[j], acc[t][j]);
                 }
             }
+            x += 32;
+            while (x >= p.W) { x -= p.W; ++y; }
         }
         // ---- block combine: red[pixel lane][cg][72] over the tile's LDS (the launch allocates >= 73,728 B)
         __syncthreads();
@@ -455,8 +463,8 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
 // rows per tile, 0 = shape not taken (then the older kernels run).  Two blocks per CU when the tile fits
 // in 80 KiB (one block stages while the other computes), else one block of up to 150 KiB.
 inline int dw3_rows(int H, int W, int dil, bool wgrad) {
-    const long row_bytes = (long)W * 128;
-    long th = (80 * 1024) / row_bytes - 2 * dil;
+    const long row_bytes = (long)(W + 2 * dil) * 128;
+    long th = (80 * 1024 - 1024) / row_bytes - 2 * dil;
     if (th < 1 || th < dil) th = (150 * 1024) / row_bytes - 2 * dil;
     if (th > H) th = H;
     if (wgrad && th * W > 32 * kDw3MaxPx) th = (32 * kDw3MaxPx) / W;
@@ -473,7 +481,7 @@ inline int launch_dw3(const void* in, const void* in2, const void* w9, void* out
           (unsigned)in_bytes};
     const long nb = (long)N * p.tiles_h;
     if (nb > 0x7fffffffL) return -4;
-    int lds = (TH + 2 * dil) * W * 128 + 1024;                  // + one wave-instruction of slack for the tail
+    int lds = (TH + 2 * dil) * (W + 2 * dil) * 128 + 1024;      // + one wave-instruction of slack for the tail
     if (MODE == 2 && lds < 32 * 8 * 72 * 4) lds = 32 * 8 * 72 * 4;
     if (lds > 160 * 1024) return -2;
     auto kfn = dwconv3_kernel<MODE>;

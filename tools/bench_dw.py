@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Depthwise 3x3 micro-benchmark (csrc/depthwise.hip) on the Xception-65 OS8 shapes.
+
+    python tools/bench_dw.py [--batch 16]
+Prints us per call and the effective HBM rate of the ideal traffic (fwd / dgrad: read + write one
+tensor; wgrad: read two)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributedpytorch_amd import ops  # noqa: E402
+
+SHAPES = [  # name, count, C, HW, dil
+    ("entry.128@129", 2, 128, 129, 1),
+    ("entry.256@65", 2, 256, 65, 1),
+    ("middle.728@65.d2", 51, 728, 65, 2),
+    ("exit.1024@65.d2", 1, 1024, 65, 2),
+    ("exit.1536@65.d4", 2, 1536, 65, 4),
+]
+
+
+def timeit(fn, iters=5, inner=10):
+    fn()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / inner)
+    return sorted(ts)[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    args = ap.parse_args()
+    from distributedpytorch_amd.ops import _hip_conv
+    tot = [0.0, 0.0, 0.0]
+    for name, cnt, c, hw, d in SHAPES:
+        x = torch.randn(args.batch, c, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(c, 1, 3, 3, device="cuda")
+        w16 = w.to(torch.bfloat16)
+        xg = x.clone().requires_grad_(True)
+        wg = w.clone().requires_grad_(True)
+        y = _hip_conv._DepthwiseConv.apply(xg, wg, w16, (1, 1), (d, d), (d, d))
+        dy = torch.randn_like(y)
+        t_f = timeit(lambda: _hip_conv._DepthwiseConv.apply(x, w, w16, (1, 1), (d, d), (d, d)))
+        t_dx = timeit(lambda: torch.autograd.grad(y, xg, dy, retain_graph=True))
+        t_all = timeit(lambda: torch.autograd.grad(y, (xg, wg), dy, retain_graph=True))
+        t_w = t_all - t_dx
+        mb = x.numel() * 2 / 1e6
+        print(f"{name:18s} x{cnt:2d} {mb:7.1f} MB | fwd {t_f:7.1f} us ({2 * mb / t_f:5.2f} TB/s) | dgrad {t_dx:7.1f} us "
+              f"({2 * mb / t_dx:5.2f} TB/s) | wgrad {t_w:7.1f} us ({2 * mb / t_w:5.2f} TB/s)", flush=True)
+        for i, t in enumerate((t_f, t_dx, t_w)):
+            tot[i] += cnt * t
+    print(f"TOTAL ms/step: fwd {tot[0] / 1e3:.2f}  dgrad {tot[1] / 1e3:.2f}  wgrad {tot[2] / 1e3:.2f}")
+
+
+if __name__ == "__main__":
+    main()
