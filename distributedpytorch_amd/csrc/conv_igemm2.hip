@@ -24,6 +24,7 @@
 //     where (out − pad + r·dil) is a multiple of sdiv, and there floor(base/sdiv) + ceil(tap/sdiv)
 //     is exact, so the per-lane base and the uniform tap offset stay separable.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -64,6 +65,8 @@ struct Conv2Args {
     int csteps, ksteps, ctail;
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes;
+    int ablate;             // diagnostics only (dp_conv_set_ablate): 1 = no LDS-DMA in the K loop,
+                            // 4 = no fragment reads and no MFMA; results are garbage, the TIME tells the bound
 };
 
 template <int N>
@@ -95,7 +98,19 @@ __device__ __forceinline__ int chunk_swz(int row) {
     return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64>
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4v;
+
+__device__ __forceinline__ void lds_read16(i32x4v& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+// PIPE: fragment reads are software-pipelined against the MFMAs by hand (see the K loop).
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64, bool PIPE = true>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2Args p) {
     constexpr int T = 64 * WGM * WGN;
     constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
@@ -248,11 +263,64 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of the buffer about to be refilled are done
         __builtin_amdgcn_s_barrier();
-        if (t + NST - 1 < ksteps) {
+        if (t + NST - 1 < ksteps && !(p.ablate & 1)) {
             int ib = buf + NST - 1;
             if (ib >= NST) ib -= NST;
             issue_stage(ib);
         }
+        if (p.ablate & 4) { if (++buf == NST) buf = 0; continue; }
+        if (PIPE) {
+            // Left to itself hipcc sinks every fragment read to just before its first MFMA (2 reads, wait,
+            // 8 MFMAs, 2 reads, wait, ...: the ISA of the first version), so each wave exposes an LDS
+            // round trip per pair of pixel tiles and reads and MFMAs of a wave never overlap — the time of
+            // a step was reads + MFMAs (tools/ablate_conv.py: 421 + 526 us of a 993 us loop).  Here the
+            // reads are inline asm in a fixed order: the NEXT group of pixel-tile fragments (and, at the end
+            // of a 32-wide half, the next half's weight fragments) is issued BEFORE the MFMAs of the
+            // current group, and each group waits with a COUNTED lgkmcnt for exactly what it consumes.
+            constexpr int KK = BK / 32;
+            constexpr int PA = MI % 2 == 0 ? 2 : 1;            // pixel tiles per fragment group
+            constexpr int G = MI / PA;                         // groups per 32-wide half
+            const unsigned sb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + buf * STAGE;
+            const unsigned xa0 = sb + x_row_off + ch0, xa1 = sb + x_row_off + ch1;
+            const unsigned wa0 = sb + w_row_off + ch0, wa1 = sb + w_row_off + ch1;
+            i32x4v wfr[2][NI], xfr[2][PA];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) lds_read16(wfr[0][ni], wa0 + ni * (16 * ROWB));
+#pragma unroll
+            for (int a = 0; a < PA; ++a) lds_read16(xfr[0][a], xa0 + a * (16 * ROWB));
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int cur = (kk * G + g) & 1;
+                    int newer = 0;                             // reads issued after the ones this group consumes
+                    if (g + 1 < G) {
+#pragma unroll
+                        for (int a = 0; a < PA; ++a)
+                            lds_read16(xfr[cur ^ 1][a], (kk == 0 ? xa0 : xa1) + ((g + 1) * PA + a) * (16 * ROWB));
+                        newer = PA;
+                    } else if (kk + 1 < KK) {
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) lds_read16(wfr[(kk + 1) & 1][ni], wa1 + ni * (16 * ROWB));
+#pragma unroll
+                        for (int a = 0; a < PA; ++a) lds_read16(xfr[cur ^ 1][a], xa1 + a * (16 * ROWB));
+                        newer = NI + PA;
+                    }
+                    if (newer == 0) wait_lgkm<0>();
+                    else if (newer == PA) wait_lgkm<PA>();
+                    else wait_lgkm<NI + PA>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < PA; ++a)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[g * PA + a][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, wfr[kk & 1][ni]), __builtin_bit_cast(bf16x8, xfr[cur][a]),
+                                acc[g * PA + a][ni], 0, 0, 0);
+                }
+            }
+        } else {
         const unsigned char* St = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -269,6 +337,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+        }
         }
         if (++buf == NST) buf = 0;
     }
@@ -453,6 +522,21 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
     constexpr int epi_bytes = BM * (BN * 2 + 8) + WGM * 2 * BN * 4;
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
+    static const bool pipe = !(getenv("DPAMD_CONV_PIPE") && atoi(getenv("DPAMD_CONV_PIPE")) == 0);
+    if (!pipe) {
+        if (unit) {
+            auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK, false>;
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
+        } else {
+            auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false, BK, false>;
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
+        }
+        return DP_LAUNCH_STATUS();
+    }
     if (unit) {
         auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK>;
         if (lds > 64 * 1024) {
@@ -499,7 +583,10 @@ thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
 thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
+int g_ablate = 0;
 }  // namespace
+
+DP_EXPORT int dp_conv_set_ablate(int mask) { g_ablate = mask; return 0; }
 
 // + res: optional [N*Ho*Wo, ldres] bf16 tensor added to the output (not part of the fused statistics)
 DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
@@ -529,6 +616,7 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.M = (int)((long)N * Ho * Wo);
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
     p.ldx = ldx;
+    p.ablate = g_ablate;
     p.smul = smul; p.sdl = sdiv == 1 ? 0 : (sdiv == 2 ? 1 : 2);
     p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
     p.ldy = ldy;
