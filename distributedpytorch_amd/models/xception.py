@@ -43,8 +43,9 @@ class _Unit(nn.Module):
         self.bn = BatchNorm2d(cout)
         self.relu_after = relu_after
 
-    def forward(self, x):
-        return conv_bn_act(self.sep.pointwise, self.bn, self.sep.depthwise_bn(x), relu=self.relu_after)
+    def forward(self, x, residual=None, relu=None):
+        return conv_bn_act(self.sep.pointwise, self.bn, self.sep.depthwise_bn(x),
+                           relu=self.relu_after if relu is None else relu, residual=residual)
 
 
 class XceptionBlock(nn.Module):
@@ -52,6 +53,12 @@ class XceptionBlock(nn.Module):
                  start_with_relu: bool = True, grow_first: bool = True, is_last: bool = False):
         super().__init__()
         self.start_with_relu = start_with_relu
+        # set by AlignedXception: every consumer of this block's output applies a ReLU first, so the block
+        # emits relu(out) from its last fused BN kernel (BN + shortcut + ReLU in one pass: no add kernel,
+        # no separate ReLU forward / backward over the 728-channel maps) ...
+        self.activate_output = False
+        # ... and the block that receives such an input does not activate it again
+        self.input_activated = False
         if cout != cin or stride != 1:
             self.skip = Conv2d(cin, cout, 1, stride=stride, bias=False)
             self.skipbn = BatchNorm2d(cout)
@@ -76,13 +83,15 @@ class XceptionBlock(nn.Module):
         self.rep = nn.Sequential(*units)
 
     def forward(self, inp):
-        x = torch.relu(inp) if self.start_with_relu else inp
+        x = torch.relu(inp) if (self.start_with_relu and not self.input_activated) else inp
         # pre-activation quirk of the published weights: the shortcut sees the activated input
         short = x
-        x = self.rep(x)
         if self.skip is not None:
-            return conv_bn_act(self.skip, self.skipbn, short, residual=x)
-        return x + short
+            x = self.rep(x)
+            return conv_bn_act(self.skip, self.skipbn, short, residual=x, relu=self.activate_output)
+        for unit in list(self.rep)[:-1]:
+            x = unit(x)
+        return self.rep[-1](x, residual=short, relu=self.activate_output)
 
 
 class AlignedXception(nn.Module):
@@ -113,17 +122,22 @@ class AlignedXception(nn.Module):
         self.bn5 = BatchNorm2d(2048)
         self.out_channels, self.low_level_channels = 2048, 128
         self.output_stride = output_stride
+        # every block output is consumed through a ReLU (the next block's pre-activation, `low`, the
+        # ReLU before conv3): produce it activated
+        chain = [self.block1, self.block2, self.block3, *self.middle, self.block20]
+        for blk in chain:
+            blk.activate_output = True
+        for blk in chain[1:]:
+            blk.input_activated = True
 
     def forward(self, x):
         x = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         x = conv_bn_act(self.conv2, self.bn2, x, relu=True)
-        x = self.block1(x)
-        low = torch.relu(x)
+        low = self.block1(x)              # = relu(block output): see activate_output
         x = self.block2(low)
         x = self.block3(x)
         x = self.middle(x)
         x = self.block20(x)
-        x = torch.relu(x)
         x = conv_bn_act(self.conv3.pointwise, self.bn3, self.conv3.depthwise_bn(x), relu=True)
         x = conv_bn_act(self.conv4.pointwise, self.bn4, self.conv4.depthwise_bn(x), relu=True)
         x = conv_bn_act(self.conv5.pointwise, self.bn5, self.conv5.depthwise_bn(x), relu=True)

@@ -192,6 +192,8 @@ class _BatchNormActTrain(torch.autograd.Function):
         need_dres = ctx.has_res and ctx.needs_input_grad[3]
         mask_mode = ctx.mask_mode if ctx.hip else 0
         fused_dres = None
+        if ctx.hip and need_dres and ctx.mask_mode == 0:
+            fused_dres, need_dres = dy, False        # no activation: the residual's gradient IS dy (no copy)
         h = ctx.holder
         if ctx.hip and h is not None and h.get("dm_ptr") == dy.data_ptr() and h.get("sums") is not None:
             # the consumer's data-gradient kernel already applied the ReLU mask to dy and left the two
