@@ -155,7 +155,9 @@ def train_epoch(engine, loader, sampler, scheduler, epoch, args, log):
     running = torch.zeros((), device=engine.device)
     n_iter, n_img = 0, 0
     t0 = timeit.default_timer()
+    data_wait, t_fetch = 0.0, timeit.default_timer()
     for ii, batch in enumerate(loader):
+        data_wait += timeit.default_timer() - t_fetch          # host time blocked on the loader workers
         if args.max_iters and ii >= args.max_iters:
             break
         scheduler(engine.optimizer, ii, epoch)
@@ -167,9 +169,14 @@ def train_epoch(engine, loader, sampler, scheduler, epoch, args, log):
         if args.log_every and (ii + 1) % args.log_every == 0:
             dist_env.check_finite_or_abort(loss, engine.global_step)   # one host sync per log interval
             dt = timeit.default_timer() - t0
+            extra = {}
+            if engine.on_gpu:
+                extra["hbm_peak_gib"] = torch.cuda.max_memory_allocated(engine.device) / 2 ** 30
             log.log("train", epoch=epoch, iter=ii + 1, loss=float(running) / n_iter,
                     lr=engine.optimizer.param_groups[0]["lr"],
-                    img_per_s=n_img * dist_env.get_world_size() / dt, **engine.timer.summary())
+                    img_per_s=n_img * dist_env.get_world_size() / dt,
+                    data_wait_ms=1e3 * data_wait / n_iter, **extra, **engine.timer.summary())
+        t_fetch = timeit.default_timer()
     mean_loss = dist_env.all_reduce_scalar(float(running) / max(n_iter, 1), "sum", engine.device
                                            if engine.on_gpu else None) / dist_env.get_world_size()
     dt = timeit.default_timer() - t0
