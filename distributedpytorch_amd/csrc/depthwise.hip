@@ -318,6 +318,8 @@ struct Dw3 {
     const bf16_raw* in; const bf16_raw* in2; const bf16_raw* w9; void* out;
     int N, C, H, W, dil, TH, tiles_h, flip;
     unsigned in_bytes;
+    float* stats;           // MODE 0: optional [stat_reps][2][C] per-channel sums of out and out^2 (BatchNorm
+    int stat_reps;          //   batch statistics for free, as in the dense kernels' epilogue)
 };
 
 constexpr unsigned kOOBd = 0x80000000u;
@@ -392,6 +394,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int q = 0; q < 3; ++q) toff[a * 3 + q] = (a * d * Wt + q * d) * 8;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
         int y = pl / p.W, x = pl - y * p.W;             // pl < 32: at most a few rows down
         for (int pi = pl; pi < npix; pi += 32) {
             const uint4* t0 = tile + (y * Wt + x) * 8 + cg;
@@ -406,8 +411,30 @@ __global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[t][j], acc[j]);
             }
             if (cg_ok) *reinterpret_cast<uint4*>(out + (long)pi * p.C) = pack8(acc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
             x += 32;
             while (x >= p.W) { x -= p.W; ++y; }
+        }
+        if (p.stats) {                                   // uniform
+            __syncthreads();                             // everyone is done with the tile
+            float* red = reinterpret_cast<float*>(smem3);       // [32 pixel lanes][8 cg][16]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(pl * 8 + cg) * 16 + j] = s1[j];
+                red[(pl * 8 + cg) * 16 + 8 + j] = s2[j];
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int g = tid >> 4, e = tid & 15;
+                if (g < ncg) {
+                    float v = 0.f;
+#pragma unroll 8
+                    for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 16 + e];
+                    float* dst = p.stats + (long)(blockIdx.x % p.stat_reps) * 2 * p.C;
+                    atomicAdd(dst + (e >> 3) * p.C + c0 + g * 8 + (e & 7), v);
+                }
+            }
         }
     } else {
         float acc[9][8];
@@ -474,15 +501,16 @@ inline int dw3_rows(int H, int W, int dil, bool wgrad) {
 
 template <int MODE>
 inline int launch_dw3(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
-                      int flip, int TH, hipStream_t st) {
+                      int flip, int TH, hipStream_t st, float* stats = nullptr, int stat_reps = 1) {
     const long in_bytes = (long)N * H * W * C * 2;
     if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
     Dw3 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TH, (H + TH - 1) / TH, flip,
-          (unsigned)in_bytes};
+          (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps};
     const long nb = (long)N * p.tiles_h;
     if (nb > 0x7fffffffL) return -4;
     int lds = (TH + 2 * dil) * (W + 2 * dil) * 128 + 1024;      // + one wave-instruction of slack for the tail
     if (MODE == 2 && lds < 32 * 8 * 72 * 4) lds = 32 * 8 * 72 * 4;
+    if (MODE == 0 && stats && lds < 32 * 8 * 16 * 4) lds = 32 * 8 * 16 * 4;
     if (lds > 160 * 1024) return -2;
     auto kfn = dwconv3_kernel<MODE>;
     static bool once = false;
@@ -576,4 +604,17 @@ DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3((unsigned)nb, (unsigned)((C8 + 255) / 256)), dim3(256), 0, st,
                        (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p);
     return DP_LAUNCH_STATUS();
+}
+
+// Forward with fused BatchNorm statistics: stats fp32 [stat_reps][2][C], zero-initialised, receives the
+// per-channel sums of y and y^2.  Returns -2 when the LDS row-tiled kernel does not take the shape (the
+// caller then runs dp_dwconv_fwd and a separate statistics pass).
+DP_EXPORT int dp_dwconv_fwd_stats(const void* x, const void* w9, void* y, float* stats, int stat_reps, int N, int C,
+                                  int Hi, int Wi, int Ho, int Wo, int stride, int pad_h, int pad_w, int dil,
+                                  hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || !stats || stat_reps < 1) return -1;
+    if (!(kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi)) return -2;
+    const int th = dw3_rows(Hi, Wi, dil, false);
+    if (th <= 0) return -2;
+    return launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st, stats, stat_reps);
 }

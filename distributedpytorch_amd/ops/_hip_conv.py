@@ -38,6 +38,7 @@ def _lib():
         lib.dp_conv_igemm2w.argtypes = [V, V, V, V, V] + [I] * 19 + [V]
         lib.dp_conv_wgrad_win.argtypes = [V, V, V] + [I] * 12 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
+        lib.dp_dwconv_fwd_stats.argtypes = [V, V, V, V] + [I] * 11 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 10 + [V]
         _sigs_done = True
@@ -546,7 +547,7 @@ class _StemConv(torch.autograd.Function):
 
 class _DepthwiseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, w_lowp, stride, padding, dilation):
+    def forward(ctx, x, weight, w_lowp, stride, padding, dilation, with_stats=False):
         c = x.shape[1]
         n, _, hi, wi = x.shape
         if weight.shape[2:] != (3, 3) or c % 8:
@@ -556,14 +557,36 @@ class _DepthwiseConv(torch.autograd.Function):
         wo = _out_size(wi, 3, stride[1], padding[1], dilation[1])
         w9 = w_lowp.reshape(c, 9).t().contiguous()  # [9][C]: tap-major so 8 channels are one 16-B load
         y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        B.check(_lib().dp_dwconv_fwd(B.ptr(x), B.ptr(w9), B.ptr(y), n, c, hi, wi, ho, wo, stride[0], padding[0],
-                                     padding[1], dilation[0], B.stream_ptr()), "dwconv_fwd")
+        ctx.set_materialize_grads(False)
+        stats = None
+        if with_stats:
+            # BatchNorm statistics from the kernel's own accumulators (csrc/depthwise.hip, Dw3::stats)
+            reps = stat_replicas(n * ho * wo)
+            stats = workspace.zeros(reps * 2 * c, x.device).view(reps, 2, c)
+            st = _lib().dp_dwconv_fwd_stats(B.ptr(x), B.ptr(w9), B.ptr(y), B.ptr(stats), reps, n, c, hi, wi, ho, wo,
+                                            stride[0], padding[0], padding[1], dilation[0], B.stream_ptr())
+            if st == -2:
+                stats = None                     # shape not taken by the tiled kernel: separate pass below
+            else:
+                B.check(st, "dwconv_fwd_stats")
+        if stats is None:
+            B.check(_lib().dp_dwconv_fwd(B.ptr(x), B.ptr(w9), B.ptr(y), n, c, hi, wi, ho, wo, stride[0], padding[0],
+                                         padding[1], dilation[0], B.stream_ptr()), "dwconv_fwd")
         ctx.save_for_backward(x, w9)
         ctx.geom = (stride, padding, dilation, (hi, wi), (ho, wo))
+        if with_stats:
+            if stats is None:
+                from . import _hip_bn
+                s1, s2 = _hip_bn.stats(y)
+                stats = torch.stack([s1, s2]).unsqueeze(0)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
+        if dy is None:
+            return (None,) * 7
         x, w9 = ctx.saved_tensors
         stride, padding, dilation, (hi, wi), (ho, wo) = ctx.geom
         n, c = x.shape[:2]
@@ -579,7 +602,7 @@ class _DepthwiseConv(torch.autograd.Function):
                                                 padding[0], padding[1], dilation[0], B.stream_ptr()),
                     "dwconv_bwd_weight")
             dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False, passthrough=False,
@@ -596,12 +619,12 @@ def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stat
                                 holder)
     if passthrough:
         raise NotImplementedError("passthrough is a dense-convolution feature")
-    if with_stats:
-        raise NotImplementedError("fused statistics are only produced by the dense implicit-GEMM kernel")
     if groups == x.shape[1] == weight.shape[0] and weight.shape[1] == 1:
         if bias is not None:
             raise NotImplementedError("depthwise bias")
         if dilation[0] != dilation[1] or stride[0] != stride[1]:
             raise NotImplementedError("anisotropic depthwise")
-        return _DepthwiseConv.apply(x, weight, w_lowp, stride, padding, dilation)
+        return _DepthwiseConv.apply(x, weight, w_lowp, stride, padding, dilation, with_stats)
+    if with_stats:
+        raise NotImplementedError("fused statistics: dense and depthwise convolutions only")
     raise NotImplementedError(f"grouped convolution with groups={groups} (only dense and depthwise)")

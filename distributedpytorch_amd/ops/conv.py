@@ -121,7 +121,10 @@ class Conv2d(nn.Module):
                 and torch.is_grad_enabled() and x.requires_grad)
 
     def can_fuse_stats(self, x: torch.Tensor) -> bool:
-        return (B.use_hip(x) and self.groups == 1 and self.out_channels % 8 == 0
+        dense = self.groups == 1
+        depthwise = (self.groups == self.in_channels == self.out_channels and self.kernel_size == (3, 3)
+                     and self.bias is None)
+        return (B.use_hip(x) and (dense or depthwise) and self.out_channels % 8 == 0
                 and x.dtype == torch.bfloat16)
 
     def extra_repr(self) -> str:

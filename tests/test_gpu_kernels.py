@@ -220,8 +220,11 @@ def test_depthwise(stride, dil, shape):
     gy = _bf(torch.randn_like(yr)).to(DEV)
     yr.backward(gy.float().cpu())
     xh, wh = _nhwc(x).requires_grad_(True), wt.float().requires_grad_(True)
-    yh = ops.conv2d(xh, wh, None, stride, dil, dil, groups=c)
+    yh, stats = ops.conv2d(xh, wh, None, stride, dil, dil, groups=c, with_stats=True)
     assert _rel(yh, yr) < 1.5e-2
+    st = stats.sum(0).cpu()                  # fused in the tiled kernel, a separate pass behind the flat ones
+    assert _rel(st[0], yr.detach().sum(dim=(0, 2, 3))) < 2e-2
+    assert _rel(st[1], (yr.detach() ** 2).sum(dim=(0, 2, 3))) < 2e-2
     yh.backward(_nhwc(gy))
     assert _rel(xh.grad, xr.grad) < 1.5e-2
     assert _rel(wh.grad, wr.grad) < 1.5e-2
