@@ -421,6 +421,16 @@ inline dim3 grid_for(long M, int C, int rows_per_thread) {
     return dim3((unsigned)nb, (unsigned)((C8 + kThreads - 1) / kThreads), 1);
 }
 
+// Streaming kernels: threads beyond rpp * cgs have no rows (make_map: rlane >= rpp).  With 91 channel
+// groups (728 channels, Xception) that is 74 of 256 — launch only the waves that hold active threads
+// (192), so the CU's wave slots go to blocks that move data.
+inline dim3 block_for(int C) {
+    const int C8 = C / 8;
+    const int cgs = C8 < kThreads ? C8 : kThreads;
+    const int used = (kThreads / cgs) * cgs;
+    return dim3((unsigned)((used + 63) / 64 * 64));
+}
+
 // reduction kernels: grid = (row splits, 64-channel slabs); ~1024 blocks in total, ≥ 8 rows/thread
 inline dim3 grid_reduce(long M, int C) {
     const int C8 = C / 8;
@@ -497,7 +507,7 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
     a.drop = take_drop();
     a.y_ld8 = take_ld8(C);
     if (a.y_ld8 * 8 < C || ((uintptr_t)y & 15)) return -1;
-    hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), block_for(C), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
 
@@ -509,7 +519,7 @@ DP_EXPORT int dp_bn_apply_affine(const void* x, const void* res, void* y, long M
     a.scale = scale; a.shift = shift; a.relu = relu;
     a.y_ld8 = take_ld8(C);
     if (a.y_ld8 * 8 < C || ((uintptr_t)y & 15)) return -1;
-    hipLaunchKernelGGL(bn_apply_kernel<false>, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid_for(M, C, 4), block_for(C), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
 
@@ -542,6 +552,6 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     a.drop = take_drop();
     a.dy_ld8 = take_ld8(C);
     if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), block_for(C), 0, st, a);
     return DP_LAUNCH_STATUS();
 }
