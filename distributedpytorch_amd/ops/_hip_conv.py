@@ -119,13 +119,27 @@ _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
 # 64-wide 2-stage counterparts on every R101 layer at batch 128 (profiles/r1_conv_cfg_sweep_b128.log)
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 0)
 _TUNED: dict = {}
+
+
+def _load_tuned(path: str) -> None:
+    import json as _json
+    with open(path) as _f:
+        _TUNED.update({tuple(tuple(v) if isinstance(v, list) else v for v in _json.loads(k)): c
+                       for k, c in _json.load(_f).items()})
+
+
+# Packaged table for the headline problem (DeepLabv3+ R101, 513², per-GPU batch 128 on MI355X): the
+# majority choice of three autotune runs (gpurun_out/s63).  Every rank then runs the SAME tiles from the
+# first step — per-rank tuning noise flips near-ties (20 of 101 problems differed between runs), and under
+# data parallelism the slowest rank's choice gates every step.  Problems not in the table are measured as
+# before; DPAMD_CONV_TUNE_TABLE=0 ignores the table.
+_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+if os.environ.get("DPAMD_CONV_TUNE_TABLE", "1") != "0" and os.path.isfile(_TABLE):
+    _load_tuned(_TABLE)
 # optional cross-process cache of the measured choices (JSON): set DPAMD_CONV_TUNE_FILE
 _TUNE_FILE = os.environ.get("DPAMD_CONV_TUNE_FILE")
 if _TUNE_FILE and os.path.isfile(_TUNE_FILE):
-    import json as _json
-    with open(_TUNE_FILE) as _f:
-        _TUNED.update({tuple(tuple(v) if isinstance(v, list) else v for v in _json.loads(k)): c
-                       for k, c in _json.load(_f).items()})
+    _load_tuned(_TUNE_FILE)
 
 
 def _save_tuned() -> None:
