@@ -232,12 +232,21 @@ __device__ __forceinline__ void lds_dma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned
                                              soff, 0, 0);
 }
 
-template <bool UNIT>
-__global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) {
+// G = 2: two 128-channel dy sub-tiles share ONE x tile in a block of 8 waves (waves 0-3 own sub-tile 0,
+// waves 4-7 sub-tile 1; each group is the 4-wave kernel unchanged, the x tile is loaded once by all 8).
+// A K-step then moves 48 KiB for 256x128x64 MACs instead of 2 x 32 KiB: the kernel is bound by the
+// L2->LDS stream (README, "Where the time goes"), and the weight gradients cost the critical path 26 ms
+// of a 146 ms step even on their own stream (gpurun_out/s66: 120 ms without them).
+template <bool UNIT, int G>
+__global__ __launch_bounds__(kThreads * G, 2) void conv_wgrad2_kernel(Wgrad2Args p) {
+    constexpr int XOFF = G * TILE_BYTES;                 // x tile offset inside a stage
+    constexpr int STG = (G + 1) * TILE_BYTES;            // bytes per stage
+    constexpr int NR = 4 / G;                            // x load rounds per thread (16*G rows each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
     const int split = bid / tiles;
     const int tile = bid - split * tiles;
     const int tile_k = tile % p.tiles_k, tile_n = tile / p.tiles_k;
-    const int k0 = tile_k * TM, n0 = tile_n * TN;
+    const int k0 = tile_k * (TM * G) + grp * TM, n0 = tile_n * TN;     // k0: this wave group's first channel
     const int p_begin = split * p.px_per_split;
     const int p_end = min(p.P, p_begin + p.px_per_split);
     const int nsteps = (p_end - p_begin + TP - 1) / TP;
@@ -261,9 +270,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
 
     const int pc = lane & 15;
     const int rsub = lane >> 4;
-    const int fsw = (rsub << 2) | wave;
+    const int fsw = (rsub << 2) | w4;                  // f(row): row & 3 = rsub, (row >> 2) & 3 = wave & 3
     const int lc = pc ^ fsw;
-    const int row0 = wave * 4 + rsub;                  // + 16·i for load round i
+    const int row0 = w4 * 4 + rsub;                    // dy: + 16·i for load round i (per wave group)
+    const int xrow0 = wave * 4 + rsub;                 // x:  + 16·G·i (all waves share the tile)
 
     // dy operand: channels k0 + lc*8 .. +7 of pixel (p_begin + row)
     const int kch = k0 + lc * 8;
@@ -280,11 +290,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
     const int cch = flat - tap * p.Cin;
     const int tr = tap / p.S, ts = tap - tr * p.S;
     const int tdy = tr * p.dil_h - p.pad_h, tdx = ts * p.dil_w - p.pad_w;
-    unsigned x_voff[4];                                 // UNIT: fixed offsets; general: byte offset of the
-    int pox[4], poy[4];                                 //   row's input pixel (oy·sh, ox·sw) before the tap
+    unsigned x_voff[NR];                                // UNIT: fixed offsets; general: byte offset of the
+    int pox[NR], poy[NR];                               //   row's input pixel (oy·sh, ox·sw) before the tap
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int px = p_begin + i * 16 + row0;
+    for (int i = 0; i < NR; ++i) {
+        const int px = p_begin + i * (16 * G) + xrow0;
         if (UNIT) {
             x_voff[i] = n_ok ? (unsigned)((px * p.Cin + cch) * 2) : kOOBw;
         } else {
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
     // in the VGPR offsets (one v_add per load and step) and the SGPR offset stays 0.  An out-of-range
     // lane starts at 2^31 and the tensors are < 2^31 - 2^24 bytes: it stays out of range, no wrap.
     auto issue_stage = [&](int buf) {
-        unsigned char* dbase = smem + buf * STAGE + wave * 1024;
-        unsigned char* xbase = dbase + TILE_BYTES;
+        unsigned char* dbase = smem + buf * STG + grp * TILE_BYTES + w4 * 1024;
+        unsigned char* xbase = smem + buf * STG + XOFF + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             lds_dma16w(rdy, dbase + i * 4096, dy_voff[i], 0);
@@ -316,17 +326,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
         }
         if (UNIT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lds_dma16w(rx, xbase + i * 4096, x_voff[i], 0);
+            for (int i = 0; i < NR; ++i) {
+                lds_dma16w(rx, xbase + i * (4096 * G), x_voff[i], 0);
                 x_voff[i] += x_step;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int iy = poy[i] * p.stride_h + tdy, ix = pox[i] * p.stride_w + tdx;
                 const bool ok = n_ok & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
                 // pixels beyond P have n >= N: their offset lies beyond the descriptor and reads zeros
-                lds_dma16w(rx, xbase + i * 4096, ok ? x_voff[i] + (unsigned)tap_bytes : kOOBw, 0);
+                lds_dma16w(rx, xbase + i * (4096 * G), ok ? x_voff[i] + (unsigned)tap_bytes : kOOBw, 0);
                 pox[i] += adv_x; poy[i] += adv_y; x_voff[i] += adv_bytes;
                 if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; x_voff[i] += wrapx_bytes; }
                 while (poy[i] >= p.Ho) { poy[i] -= p.Ho; x_voff[i] += wrapy_bytes; }
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = w4 >> 1, wn = w4 & 1;
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     int offA[2][2], offB[2][2];
 #pragma unroll
@@ -369,8 +379,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
-                aA[t][rd] = base + (unsigned)offA[t][rd];
-                aB[t][rd] = base + TILE_BYTES + (unsigned)offB[t][rd];
+                aA[t][rd] = base + (unsigned)(grp * TILE_BYTES) + (unsigned)offA[t][rd];
+                aB[t][rd] = base + (unsigned)XOFF + (unsigned)offB[t][rd];
             }
     }
     s16x4 fa[2][2][2], fb[2][2][2];                     // [set][sub-tile][rd]
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad2_kernel(Wgrad2Args p) 
                                                               __builtin_bit_cast(bf16x8, vb), acc[i_][j_], 0, 0, 0); \
     }
 
-    unsigned flip = (unsigned)STAGE;
+    unsigned flip = (unsigned)STG;
     if (nsteps > 0) issue_stage(0);
     for (int t = 0; t < nsteps; ++t) {
         // stage t landed (vmcnt) and my reads of the other buffer are done (every read is waited for
@@ -469,9 +479,15 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     p.P = (int)P; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
     p.stride_h = stride_h; p.stride_w = stride_w; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
     p.NF = R * S * Cin;
-    p.tiles_k = (Cout + TM - 1) / TM;
+    // two wave groups per block (256 output channels, shared x tile) when the channels fill them
+    static const int force_g = getenv("DPAMD_WGRAD_G") ? atoi(getenv("DPAMD_WGRAD_G")) : 0;
+    const long x_bytes0 = (long)N * Hi * Wi * ldx * 2;
+    const bool gen2_ok = !(reserved == 1 || x_bytes0 >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24));
+    const int G = (gen2_ok && Cout % (2 * TM) == 0 && force_g != 1) ? 2 : 1;
+    p.tiles_k = (Cout + TM * G - 1) / (TM * G);
     p.tiles_n = (p.NF + TN - 1) / TN;
     const int tiles = p.tiles_k * p.tiles_n;
+    const int slots = G == 2 ? 256 : 512;          // resident blocks chip-wide (96 KiB vs 64 KiB of LDS)
     const int steps_total = (int)((P + TP - 1) / TP);
     if (splits <= 0) {
         // Cost model (µs), calibrated on MI355X: a K-step of one block costs ~0.5 µs (LDS-DMA bound,
@@ -488,8 +504,9 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
             const int steps = (steps_total + s - 1) / s;
             const int real_s = (steps_total + steps - 1) / steps;
             const long blocks = (long)tiles * real_s;
-            const long rounds = (blocks + 511) / 512;
-            const double share = blocks >= 512 ? 1.0 : (blocks > 256 ? 0.5 + 0.5 * (blocks - 256) / 256.0 : 0.5);
+            const long rounds = (blocks + slots - 1) / slots;
+            const double share = G == 2 ? 1.0
+                                        : (blocks >= 512 ? 1.0 : (blocks > 256 ? 0.5 + 0.5 * (blocks - 256) / 256.0 : 0.5));
             const double t = rounds * (steps * share + 3.0) + (real_s > 1 ? real_s * dw_mb / 1.3 : 0.0);
             if (t < best) { best = t; best_s = real_s; }
         }
@@ -513,8 +530,20 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     q.dil_h = dil_h; q.dil_w = dil_w; q.NF = p.NF; q.tiles_k = p.tiles_k; q.tiles_n = p.tiles_n; q.splits = p.splits;
     q.px_per_split = p.px_per_split; q.x_bytes = (unsigned)x_bytes; q.ldx = ldx;
     const bool unit = R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1 && ldx == Cin;
-    if (unit) hipLaunchKernelGGL(conv_wgrad2_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
-    else hipLaunchKernelGGL(conv_wgrad2_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
+    if (G == 2) {
+        constexpr int lds2 = 2 * 3 * TILE_BYTES;      // 96 KiB
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            once = true;
+        }
+        if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 2>), dim3((unsigned)nwg), dim3(2 * kThreads), lds2, st, q);
+        else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2>), dim3((unsigned)nwg), dim3(2 * kThreads), lds2, st, q);
+        return DP_LAUNCH_STATUS();
+    }
+    if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 1>), dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
+    else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 1>), dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);
     return DP_LAUNCH_STATUS();
 }
 

@@ -310,7 +310,9 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil, runner=None) -> int:
     0.5 / 0.75 / 1 / 1.5 / 2 / 3 rounds of blocks."""
     n, hi, wi, cin, ho, wo, cout, r, s = geom
     lib, stream = _lib(), B.stream_ptr()
-    tiles = ((cout + 127) // 128) * ((r * s * cin + 127) // 128)
+    # blocks own 256 output channels when Cout fills them (csrc/conv_wgrad.hip, G = 2), else 128
+    tk = 256 if (cout % 256 == 0 and os.environ.get("DPAMD_WGRAD_G") != "1") else 128
+    tiles = ((cout + tk - 1) // tk) * ((r * s * cin + 127) // 128)
     steps_total = (n * ho * wo + 63) // 64
     cands = [0]
     for target in (256, 384, 512, 768, 1024, 1536):
@@ -440,7 +442,9 @@ class _ConvIGemm(torch.autograd.Function):
                     and wp.grad.data_ptr() == sink.data_ptr()):
                 # accumulate straight into the gradient arena (the kernel adds with fp32 atomics):
                 # no temporary, no zero-fill, no AccumulateGrad add; then tell the DDP bucketer
-                if streams.enabled():
+                if _SKIP_WGRAD:
+                    pass                 # diagnostics only: what the weight gradients cost the critical path
+                elif streams.enabled():
                     # off the critical path: runs beside the dgrad -> BN-backward chain (ops.streams)
                     aux = streams.fork(dy.device)
                     with torch.cuda.stream(aux):
@@ -468,6 +472,7 @@ class _ConvIGemm(torch.autograd.Function):
 # filter ROW becomes one tap: the S*4 <= 32 contiguous elements to the right of a pixel are that
 # pixel's "channels" (overlapping windows, pixel stride ldx = 4).  7 taps of 32, second-generation
 # kernels for forward and weight gradient, fused BN statistics as everywhere else.
+_SKIP_WGRAD = os.environ.get("DPAMD_SKIP_WGRAD") == "1"     # diagnostics: invalid training, timing only
 _STEM_WINDOW = 32
 _STEM = os.environ.get("DPAMD_STEM_WINDOW", "1") != "0"
 
