@@ -496,6 +496,9 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
                                 const float* sq, const float* weight, const float* bias, float* mean_out,
                                 float* invstd_out, float* running_mean, float* running_var, float count,
                                 float eps, float momentum, int relu, int nrep, long rep_stride, hipStream_t st) {
+    // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
+    const long ld8_ = take_ld8(C > 0 ? C : 8);
+    const Drop drop_ = take_drop();
     if (C % 8 != 0 || M <= 0) return -1;
     ApplyArgs a{};
     a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
@@ -504,8 +507,8 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
     a.inv_count = 1.f / count; a.eps = eps; a.momentum = momentum;
     a.unbias = count > 1.f ? count / (count - 1.f) : 1.f;
     a.relu = relu; a.nrep = nrep < 1 ? 1 : nrep; a.rep_stride = rep_stride;
-    a.drop = take_drop();
-    a.y_ld8 = take_ld8(C);
+    a.drop = drop_;
+    a.y_ld8 = ld8_;
     if (a.y_ld8 * 8 < C || ((uintptr_t)y & 15)) return -1;
     hipLaunchKernelGGL(bn_apply_kernel<true>, grid_for(M, C, 4), block_for(C), 0, st, a);
     return DP_LAUNCH_STATUS();
@@ -513,11 +516,13 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
 
 DP_EXPORT int dp_bn_apply_affine(const void* x, const void* res, void* y, long M, int C, const float* scale,
                                  const float* shift, int relu, hipStream_t st) {
+    // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
+    const long ld8_ = take_ld8(C > 0 ? C : 8);
     if (C % 8 != 0 || M <= 0) return -1;
     ApplyArgs a{};
     a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
     a.scale = scale; a.shift = shift; a.relu = relu;
-    a.y_ld8 = take_ld8(C);
+    a.y_ld8 = ld8_;
     if (a.y_ld8 * 8 < C || ((uintptr_t)y & 15)) return -1;
     hipLaunchKernelGGL(bn_apply_kernel<false>, grid_for(M, C, 4), block_for(C), 0, st, a);
     return DP_LAUNCH_STATUS();
@@ -526,13 +531,16 @@ DP_EXPORT int dp_bn_apply_affine(const void* x, const void* res, void* y, long M
 DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, long M, int C, const float* mean,
                                const float* invstd, const float* weight, const float* bias, float* out_sdy,
                                float* out_sdyx, int mask_mode, hipStream_t st) {
+    // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
+    const long ld8_ = take_ld8(C > 0 ? C : 8);
+    const Drop drop_ = take_drop();
     if (C % 8 != 0 || M <= 0) return -1;
     BwdArgs a{};
     a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y; a.M = M; a.C = C;
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias;
     a.out_sdy = out_sdy; a.out_sdyx = out_sdyx; a.mask_mode = mask_mode;
-    a.drop = take_drop();
-    a.dy_ld8 = take_ld8(C);
+    a.drop = drop_;
+    a.dy_ld8 = ld8_;
     if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid_reduce(M, C), dim3(kThreads), 0, st, a);
     return DP_LAUNCH_STATUS();
@@ -542,6 +550,9 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
                               const float* mean, const float* invstd, const float* weight, const float* bias,
                               const float* sdy, const float* sdyx, float count, int mask_mode, float* gw_sink,
                               float* gb_sink, const float* lsdy, const float* lsdyx, hipStream_t st) {
+    // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
+    const long ld8_ = take_ld8(C > 0 ? C : 8);
+    const Drop drop_ = take_drop();
     if (C % 8 != 0 || M <= 0) return -1;
     BwdArgs a{};
     a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y;
@@ -549,8 +560,8 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias; a.sdy = sdy; a.sdyx = sdyx;
     a.inv_count = 1.f / count; a.mask_mode = mask_mode;
     a.gw_sink = gw_sink; a.gb_sink = gb_sink; a.lsdy = lsdy; a.lsdyx = lsdyx;
-    a.drop = take_drop();
-    a.dy_ld8 = take_ld8(C);
+    a.drop = drop_;
+    a.dy_ld8 = ld8_;
     if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), block_for(C), 0, st, a);
     return DP_LAUNCH_STATUS();
