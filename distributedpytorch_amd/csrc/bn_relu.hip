@@ -276,7 +276,8 @@ struct BwdArgs {
     float* out_sdy; float* out_sdyx;       // bwd_reduce outputs
     float inv_count;
     float* gw_sink; float* gb_sink;        // optional: += local Σdy'·x̂ / Σdy' (parameter-gradient arenas)
-    const float* lsdy; const float* lsdyx; // local (pre all-reduce) sums feeding the sinks
+    const float* lsdy; const float* lsdyx; // sums feeding the sinks: local ones, or (SyncBN) the all-reduced
+    float sink_scale;                      //   ones scaled by 1/world — the same value once DDP has averaged
     long dy_ld8;    // dy row stride in 16-byte chunks (C/8, or the concat buffer's when dy is a slice of it)
     int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0, 3: as 2, and the fused
                     //    dropout's keep bit recomputed from the hash (dy' = keep·relu'·dy·scale)
@@ -369,7 +370,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
             load8f(a.lsdyx + c0, lw);
             load8f(a.lsdy + c0, lb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { a.gw_sink[c0 + j] += lw[j]; a.gb_sink[c0 + j] += lb[j]; }
+            for (int j = 0; j < 8; ++j) {
+                a.gw_sink[c0 + j] += lw[j] * a.sink_scale;
+                a.gb_sink[c0 + j] += lb[j] * a.sink_scale;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -549,7 +553,8 @@ DP_EXPORT int dp_bn_bwd_reduce(const void* dy, const void* x, const void* y, lon
 DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, void* dres, long M, int C,
                               const float* mean, const float* invstd, const float* weight, const float* bias,
                               const float* sdy, const float* sdyx, float count, int mask_mode, float* gw_sink,
-                              float* gb_sink, const float* lsdy, const float* lsdyx, hipStream_t st) {
+                              float* gb_sink, const float* lsdy, const float* lsdyx, float sink_scale,
+                              hipStream_t st) {
     // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
     const long ld8_ = take_ld8(C > 0 ? C : 8);
     const Drop drop_ = take_drop();
@@ -559,7 +564,7 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     a.dx = (bf16_raw*)dx; a.dres = (bf16_raw*)dres; a.M = M; a.C = C;
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias; a.sdy = sdy; a.sdyx = sdyx;
     a.inv_count = 1.f / count; a.mask_mode = mask_mode;
-    a.gw_sink = gw_sink; a.gb_sink = gb_sink; a.lsdy = lsdy; a.lsdyx = lsdyx;
+    a.gw_sink = gw_sink; a.gb_sink = gb_sink; a.lsdy = lsdy; a.lsdyx = lsdyx; a.sink_scale = sink_scale;
     a.drop = drop_;
     a.dy_ld8 = ld8_;
     if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;

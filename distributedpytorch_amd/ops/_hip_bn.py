@@ -25,7 +25,7 @@ def _lib():
         lib.dp_bn_bwd_reduce.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_int] + [c_void_p] * 6 + \
             [c_int, c_void_p]
         lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int] + \
-            [c_void_p] * 5
+            [c_void_p] * 4 + [c_float, c_void_p]
         lib.dp_bn_set_ld.argtypes = [c_long]
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         _sigs_done = True
@@ -183,7 +183,7 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode, dropout=None):
 
 
 def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres,
-              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None, dropout=None):
+              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None, dropout=None, sink_scale=1.0):
     _check_act(x, "x")
     dy, ld = _strided(dy, "dy", x)
     M, C = _mc(x)
@@ -204,6 +204,6 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
     B.check(_lib().dp_bn_bwd_apply(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), B.ptr(dx),
                                    B.ptr(dres), M, C, B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                    B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.ptr(gw_sink),
-                                   B.ptr(gb_sink), B.ptr(lsdy), B.ptr(lsdyx), B.stream_ptr()),
+                                   B.ptr(gb_sink), B.ptr(lsdy), B.ptr(lsdyx), float(sink_scale), B.stream_ptr()),
             "bn_bwd_apply")
     return dx, dres

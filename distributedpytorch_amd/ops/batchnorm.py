@@ -113,15 +113,28 @@ class _BatchNormActTrain(torch.autograd.Function):
             if conv_stats is not None and not sync:
                 replicas, s, ss = conv_stats, None, None      # summed inside the apply kernel
             elif conv_stats is not None:
-                red = conv_stats[0].clone() if conv_stats.shape[0] == 1 else conv_stats.sum(0)
-                s, ss = red[0], red[1]
+                from ..parallel import p2p
+                pg_ = None if group is True else group
+                if pg_ is None and p2p.ENABLED and conv_stats.numel() > p2p._MAXN:
+                    red = conv_stats.sum(0)                   # too long for the one-shot kernel's slots
+                    s, ss = red[0], red[1]
+                else:
+                    # the replicated partial sums are all-reduced IN PLACE as one message and the apply
+                    # kernel folds the replicas as on the non-synchronised path: no sum / copy kernels
+                    replicas, s, ss = conv_stats, None, None
             else:
                 s, ss = _hip_bn.stats(x)
         else:
             s, ss = _t_stats(x)
         count = float(local_count)
         pg = None if group is True else group
-        if sync and x.is_cuda:
+        if sync and x.is_cuda and replicas is not None:
+            _small_all_reduce(replicas.view(-1), pg)
+            count = float(local_count * dist.get_world_size(pg))
+            from ..parallel import debug
+            if debug.ENABLED:
+                debug.check_equal_batches(local_count, x.device)
+        elif sync and x.is_cuda:
             # C4 on the GPU: ONE message [Σx | Σx²] per layer and nothing else on the stream — the
             # [2, C] block the conv epilogue (or the statistics kernel) produced is all-reduced in
             # place (no cat / slice / copy kernels, no host round trip for the count: the sampler drops
@@ -209,12 +222,22 @@ class _BatchNormActTrain(torch.autograd.Function):
         else:
             sdy, sdyx = _t_bwd_reduce(dy, x, y, mean, invstd, ctx.relu)
         g_sdy, g_sdyx = sdy, sdyx
-        if ctx.sync:
-            # one message [Σdy' | Σdy'·x̂]; the LOCAL sums stay behind for the affine gradients
-            if sdy.is_cuda and sdy.data_ptr() + 4 * C == sdyx.data_ptr():
-                packed = torch.as_strided(sdy, (2, C), (C, 1)).clone()
+        sink_scale = 1.0
+        if ctx.sync and ctx.hip:
+            # one message [Σdy' | Σdy'·x̂], all-reduced in place.  The affine gradients then come from the
+            # GLOBAL sums scaled by 1/world: after DDP's gradient average that is the same value as
+            # averaging the local sums (Σ_r local_r / W = global / W), and no copy of the local sums is kept
+            if sdy.data_ptr() + 4 * C == sdyx.data_ptr():
+                packed = torch.as_strided(sdy, (2, C), (C, 1))
             else:
                 packed = torch.stack([sdy, sdyx])
+            _small_all_reduce(packed, ctx.pg)
+            sdy, sdyx = packed[0], packed[1]
+            g_sdy, g_sdyx = sdy, sdyx
+            sink_scale = 1.0 / dist.get_world_size(ctx.pg)
+        elif ctx.sync:
+            # one message [Σdy' | Σdy'·x̂]; the LOCAL sums stay behind for the affine gradients
+            packed = torch.stack([sdy, sdyx])
             _small_all_reduce(packed, ctx.pg)
             g_sdy, g_sdyx = packed[0], packed[1]
         if ctx.hip:
@@ -228,7 +251,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 # affine gradients are added into the gradient arena by the same kernel
                 from . import _hip_bn
                 dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                             mask_mode, need_dres, gw, gb, sdy, sdyx, ctx.dropout)
+                                             mask_mode, need_dres, gw, gb, sdy, sdyx, ctx.dropout, sink_scale)
                 if fused_dres is not None:
                     dres = fused_dres
                 for prm in (wp, bp):
@@ -247,6 +270,8 @@ class _BatchNormActTrain(torch.autograd.Function):
         # clone: the sums may live in the per-step scratch pool, autograd may keep the tensor as .grad
         dweight = sdyx.to(ctx.wdtype, copy=True) if ctx.has_affine else None
         dbias = sdy.to(ctx.wdtype, copy=True) if ctx.has_affine else None
+        if ctx.has_affine and sink_scale != 1.0:
+            dweight, dbias = dweight * sink_scale, dbias * sink_scale
         return dx, dweight, dbias, dres, None, None, None, None, None, None, None, None, None, None
 
 

@@ -65,6 +65,21 @@ def _worker(rank, world, port, sync_bn_case):
             yr.float().pow(2).sum().backward()
             assert torch.allclose(x.grad.float(), xr.grad[2 * rank:2 * rank + 2].float(), atol=5e-2, rtol=5e-2)
             assert torch.allclose(bn.running_mean, bn_ref.running_mean, atol=1e-3)
+            # affine gradients: whatever each rank holds, the SUM over the ranks (world x DDP's average) is the
+            # full-batch gradient
+            for prm, ref in ((bn.weight, bn_ref.weight), (bn.bias, bn_ref.bias)):
+                gsum = prm.grad.detach().clone()
+                dist.all_reduce(gsum)
+                assert torch.allclose(gsum, ref.grad, atol=2e-2 * float(ref.grad.abs().max()), rtol=2e-2)
+            # and through a convolution's fused statistics (replicated partial sums all-reduced in place)
+            conv = ops.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
+            torch.manual_seed(4)
+            with torch.no_grad():
+                conv.weight.copy_(torch.randn_like(conv.weight) * 0.05)
+            bn2, bn2_ref = ops.BatchNorm2d(64, sync=True).cuda().train(), ops.BatchNorm2d(64).cuda().train()
+            y2 = ops.conv_bn_act(conv, bn2, x.detach(), relu=True)
+            y2r = ops.conv_bn_act(conv, bn2_ref, xr.detach(), relu=True)
+            assert torch.allclose(y2.float(), y2r[2 * rank:2 * rank + 2].float(), atol=3e-2, rtol=3e-2)
         ar.check()
     finally:
         ar.close()
