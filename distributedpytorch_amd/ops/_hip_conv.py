@@ -99,8 +99,8 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
             st = _lib().dp_conv_igemm2r(*args, cfg, B.ptr(residual), cout, B.stream_ptr())
         else:
             st = _lib().dp_conv_igemm2(*args, cfg, B.stream_ptr())
-        if st != -2:       # -2: shape not taken by the second-generation kernel (7x7 stem, bias+stats)
-            B.check(st, "conv_igemm2")
+        if st not in (-2, -4):   # -2: shape not taken by the second-generation kernel (bias+stats, R*S > 32);
+            B.check(st, "conv_igemm2")     # -4: tensor beyond its 32-bit offsets -> first-generation kernel
             return y
     B.check(_lib().dp_conv_igemm(*args, tile, B.stream_ptr()), "conv_igemm")
     if residual is not None:
@@ -169,7 +169,7 @@ def _autotune(args, stats, reps, cout, device, runner=None, candidates=None) -> 
     timed = []
     for c in (candidates or _CANDIDATES):
         st = run(c)                      # warm-up (also tells whether the kernel takes this shape)
-        if st == -2:
+        if st in (-2, -4):               # -4: a tensor beyond the kernel's 32-bit offsets
             continue
         B.check(st, "conv autotune")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
