@@ -179,6 +179,8 @@ def _autotune(args, stats, reps, cout, device, runner=None, candidates=None) -> 
         e1.record()
         timed.append((c, e0, e1))
     torch.cuda.synchronize()
+    if not timed:
+        return 0                         # no second-generation tile takes this problem
     best = min(timed, key=lambda t: t[1].elapsed_time(t[2]))
     return best[0]
 
@@ -211,22 +213,32 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
         t = holder.get(nm)
         if t is not None and (t.dtype != torch.float32 or t.numel() != cout or not t.is_contiguous()):
             return None
-    key = (n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv, tuple(pad), tuple(dil), False, False)
+    # the fused store loop is heavier than the plain one (it reads x and the mask source): its best tile is
+    # measured on the fused launch itself
+    key = ("dgrad_bn", n, hi, wi, cin, ho, wo, cout, r, s, sdiv, tuple(pad), tuple(dil), residual is not None,
+           ba is not None)
     cfg = _FORCED_CFG if _FORCED_CFG is not None else _TUNED.get(key)
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    reps = stat_replicas(n * ho * wo)
+
+    def launch(c, sums_ptr, stream):
+        return _lib().dp_conv_igemm2b(B.ptr(dy), B.ptr(wt), B.ptr(y), n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
+                                      pad[0], pad[1], dil[0], dil[1], c, B.ptr(residual), B.ptr(bx), B.ptr(ba),
+                                      B.ptr(holder["mean"]), B.ptr(holder["invstd"]), B.ptr(holder.get("w")),
+                                      B.ptr(holder.get("b")), sums_ptr, reps, stream)
     if cfg is None:
-        args = (B.ptr(dy), B.ptr(wt), B.ptr(y), None, None, 1, n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
-                pad[0], pad[1], dil[0], dil[1], cout)
-        cfg = _TUNED[key] = _autotune(args, None, 1, cout, dy.device) if _AUTOTUNE else 1
+        if _AUTOTUNE:
+            scratch = torch.zeros(reps * 2 * cout, dtype=torch.float32, device=dy.device)
+            cfg = _autotune((), None, 1, cout, dy.device,
+                            runner=lambda a, c, stream: -2 if c == 0 else launch(c, B.ptr(scratch), stream))
+        else:
+            cfg = 1
+        _TUNED[key] = cfg
         _save_tuned()
     if cfg <= 0:
         return None
-    reps = stat_replicas(n * ho * wo)
     sums = workspace.zeros(reps * 2 * cout, dy.device).view(reps, 2, cout)
-    st = _lib().dp_conv_igemm2b(B.ptr(dy), B.ptr(wt), B.ptr(y), n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
-                                pad[0], pad[1], dil[0], dil[1], cfg, B.ptr(residual), B.ptr(bx), B.ptr(ba),
-                                B.ptr(holder["mean"]), B.ptr(holder["invstd"]), B.ptr(holder.get("w")),
-                                B.ptr(holder.get("b")), B.ptr(sums), reps, B.stream_ptr())
+    st = launch(cfg, B.ptr(sums), B.stream_ptr())
     if st == -2:
         return None
     B.check(st, "conv_igemm2b")
@@ -266,11 +278,12 @@ def stat_replicas(m_rows: int) -> int:
     return max(1, min(8, tiles // 64))
 
 
-# DPAMD_BN_PROLOGUE=1: run BN+ReLU backward's mask and reductions inside the consumer's data-gradient
-# store loop (dgrad_bn_fused).  Measured at B32 (profiles/r1_bn_prologue_ab_b32.log): 745.5 img/s
-# with it, 754.2 without — the extra tile reads sit in the MFMA kernel's epilogue where nothing hides
-# them, while bn_bwd_reduce streams at ~5 TB/s — so it is OFF by default and kept as a tested option.
-_BN_PROLOGUE = os.environ.get("DPAMD_BN_PROLOGUE", "0") != "0"
+# BN+ReLU backward's mask and reductions run inside the consumer's data-gradient store loop
+# (dgrad_bn_fused): the separate bn_bwd_reduce pass over dy and x disappears.  Measured A/B on one box
+# (gpurun_out/s80, s81): B128 905-907 vs 880-882 img/s, B64 864 vs 858, B32 809 vs 809 (the first version,
+# at B32 and before the residual/fan-out gradients moved into the store loop, was 1 % slower:
+# profiles/r1_bn_prologue_ab_b32.log).  DPAMD_BN_PROLOGUE=0 restores the separate reduction kernel.
+_BN_PROLOGUE = os.environ.get("DPAMD_BN_PROLOGUE", "1") != "0"
 # DPAMD_WGRAD_GEN=1 selects the first-generation weight-gradient kernel (A/B runs, bisection)
 _WGRAD_GEN1 = 1 if os.environ.get("DPAMD_WGRAD_GEN", "2") == "1" else 0
 
