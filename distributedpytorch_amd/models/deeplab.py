@@ -29,8 +29,9 @@ class _ASPPBranch(nn.Module):
         self.atrous_conv = Conv2d(cin, cout, k, padding=p, dilation=dilation, bias=False)
         self.bn = BatchNorm2d(cout)
 
-    def forward(self, x, passthrough: bool = False, out=None):
-        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True, passthrough=passthrough, out=out)
+    def forward(self, x, passthrough: bool = False, out=None, sole_consumer: bool = False):
+        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True, passthrough=passthrough, out=out,
+                           sole_consumer=sole_consumer)
 
 
 class _ImagePool(nn.Module):
@@ -68,7 +69,7 @@ class ASPP(nn.Module):
         # the branches write their channel slices of the concat buffer in place (ops.concat): no cat kernel
         cout = self.conv1.in_channels // 5
         cc = ChannelConcat(x, (cout,) * 5, (h, w))
-        b1, x = self.aspp1(x, passthrough=True, out=cc.slot(0))
+        b1, x = self.aspp1(x, passthrough=True, out=cc.slot(0), sole_consumer=True)   # the chain's head: whole dL/dx
         b2, x = self.aspp2(x, passthrough=True, out=cc.slot(1))
         b3, x = self.aspp3(x, passthrough=True, out=cc.slot(2))
         b4, x = self.aspp4(x, passthrough=True, out=cc.slot(3))

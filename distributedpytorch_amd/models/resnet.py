@@ -45,7 +45,9 @@ class _FanOutMixin:
     input_alias: Optional[torch.Tensor] = None
 
     def _projected(self, x):
-        out, xp = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True)
+        # x reaches its other consumers only through conv1's autograd node, so conv1's data-gradient
+        # kernel sees the WHOLE gradient of x: the producer's BN-backward prologue can run there too
+        out, xp = conv_bn_act(self.conv1, self.bn1, x, relu=True, passthrough=True, sole_consumer=True)
         if self.export_input:
             identity, xp = self.downsample(xp, passthrough=True)
             self.input_alias = xp
