@@ -279,6 +279,8 @@ struct BwdArgs {
     const float* lsdy; const float* lsdyx; // sums feeding the sinks: local ones, or (SyncBN) the all-reduced
     float sink_scale;                      //   ones scaled by 1/world — the same value once DDP has averaged
     long dy_ld8;    // dy row stride in 16-byte chunks (C/8, or the concat buffer's when dy is a slice of it)
+    int nrep;       // bwd_apply: sdy/sdyx (and lsdy/lsdyx) are nrep replicas, rep_stride floats apart — the
+    long rep_stride;//   partial sums a data-gradient store loop left behind are folded here, no sum kernel
     int mask_mode;  // 0: no activation, 1: y > 0, 2: recompute x·scale+shift > 0, 3: as 2, and the fused
                     //    dropout's keep bit recomputed from the hash (dy' = keep·relu'·dy·scale)
     Drop drop;
@@ -364,11 +366,27 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(BwdArgs a) {
         load8f(a.invstd + c0, is);
         if (a.weight) load8f(a.weight + c0, wv);
         if (a.bias) load8f(a.bias + c0, bv);
-        if (a.sdy) { load8f(a.sdy + c0, gs); load8f(a.sdyx + c0, gx); }
+        if (a.sdy) {
+            load8f(a.sdy + c0, gs); load8f(a.sdyx + c0, gx);
+            for (int r = 1; r < a.nrep; ++r) {
+                float t1[8], t2[8];
+                load8f(a.sdy + r * a.rep_stride + c0, t1);
+                load8f(a.sdyx + r * a.rep_stride + c0, t2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gs[j] += t1[j]; gx[j] += t2[j]; }
+            }
+        }
         if (a.gw_sink && blockIdx.x == 0 && m.rlane == 0) {
             float lw[8], lb[8];
             load8f(a.lsdyx + c0, lw);
             load8f(a.lsdy + c0, lb);
+            for (int r = 1; r < a.nrep; ++r) {
+                float t1[8], t2[8];
+                load8f(a.lsdyx + r * a.rep_stride + c0, t1);
+                load8f(a.lsdy + r * a.rep_stride + c0, t2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { lw[j] += t1[j]; lb[j] += t2[j]; }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 a.gw_sink[c0 + j] += lw[j] * a.sink_scale;
@@ -453,6 +471,10 @@ thread_local Drop t_drop = {0u, 1.f, 0u, 0u};
 // row strides (in elements) of the NEXT launch's y (apply) / dy (backward): set by dp_bn_set_ld, 0 = C
 thread_local long t_ld = 0;
 
+// replica count / stride (floats) of the NEXT bwd_apply launch's sums: set by dp_bn_set_sum_replicas
+thread_local int t_nrep = 1;
+thread_local long t_rep_stride = 0;
+
 inline long take_ld8(int C) {
     const long ld = t_ld > 0 ? t_ld : C;
     t_ld = 0;
@@ -483,6 +505,15 @@ DP_EXPORT int dp_bn_stats(const void* x, long M, int C, float* sum, float* sq, h
 DP_EXPORT int dp_bn_set_ld(long ld) {
     if (ld <= 0 || ld % 8 != 0) return -1;
     t_ld = ld;
+    return 0;
+}
+
+// The next dp_bn_bwd_apply launch of this thread reads sdy / sdyx (and lsdy / lsdyx) as nrep partial sums,
+// rep_stride floats apart, and folds them itself.
+DP_EXPORT int dp_bn_set_sum_replicas(int nrep, long rep_stride) {
+    if (nrep < 1 || nrep > 64 || rep_stride < 0 || rep_stride % 4 != 0) return -1;
+    t_nrep = nrep;
+    t_rep_stride = rep_stride;
     return 0;
 }
 
@@ -558,8 +589,13 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
     const long ld8_ = take_ld8(C > 0 ? C : 8);
     const Drop drop_ = take_drop();
+    const int nrep_ = t_nrep;
+    const long rep_stride_ = t_rep_stride;
+    t_nrep = 1; t_rep_stride = 0;
     if (C % 8 != 0 || M <= 0) return -1;
+    if (nrep_ > 1 && (!sdy || rep_stride_ < 2L * C)) return -1;
     BwdArgs a{};
+    a.nrep = nrep_; a.rep_stride = rep_stride_;
     a.dy = (const bf16_raw*)dy; a.x = (const bf16_raw*)x; a.y = (const bf16_raw*)y;
     a.dx = (bf16_raw*)dx; a.dres = (bf16_raw*)dres; a.M = M; a.C = C;
     a.mean = mean; a.invstd = invstd; a.weight = weight; a.bias = bias; a.sdy = sdy; a.sdyx = sdyx;

@@ -561,6 +561,11 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
 //      4 = 128x256 8-wave 3-stage   5 = 256x256 8-wave 2-stage   6 = 256x64 8-wave 3-stage
 //      7 = 128x64 4-wave 3-stage    8 = 160x128 / 9 = 192x128 4-wave 2-stage (tile-count quantisation)
 //      10 = 256x128 8-wave 2-stage   11 = 256x256 / 12 = 256x128 8-wave, 13 = 128x64 4-wave: 32-wide K steps, 4-stage ring
+//      14 = 128x128 (32-wide K, 36 KiB LDS, 4 blocks/CU)  15 = 128x64 (48 KiB, 3 blocks/CU)  16 = 192x128 (32-wide K,
+//      53 KiB, 3 blocks/CU)  17 = 256x128 / 18 = 128x256 8-wave (32-wide K, 72 KiB, 2 blocks = 16 waves/CU)
+//      small-LDS tiles for short-K layers whose time is the store loop (1x1 data gradients
+//      with the fused BN-backward prologue read three tensors per output) — more resident blocks overlap one
+//      block's K loop with another's stores
 // Returns -2 for shapes this kernel does not take (R*S > 32, bias together with stats, Cout % 8):
 // the caller then uses conv_igemm.hip.
 DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
@@ -636,6 +641,11 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
         case 11: return launch2<256, 256, 2, 4, 4, 2, 32>(p, unit, st);
         case 12: return launch2<256, 128, 4, 2, 4, 2, 32>(p, unit, st);
         case 13: return launch2<128, 64, 2, 2, 4, 1, 32>(p, unit, st);
+        case 14: return launch2<128, 128, 2, 2, 2, 4, 32>(p, unit, st);
+        case 15: return launch2<128, 64, 2, 2, 2, 3>(p, unit, st);
+        case 16: return launch2<192, 128, 2, 2, 2, 3, 32>(p, unit, st);
+        case 17: return launch2<256, 128, 4, 2, 2, 4, 32>(p, unit, st);
+        case 18: return launch2<128, 256, 2, 4, 2, 4, 32>(p, unit, st);
         default: return -2;
     }
 }

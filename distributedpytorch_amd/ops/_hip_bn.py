@@ -27,6 +27,7 @@ def _lib():
         lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int] + \
             [c_void_p] * 4 + [c_float, c_void_p]
         lib.dp_bn_set_ld.argtypes = [c_long]
+        lib.dp_bn_set_sum_replicas.argtypes = [c_int, c_long]
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         _sigs_done = True
     return lib
@@ -183,7 +184,10 @@ def bwd_reduce(dy, x, y, mean, invstd, weight, bias, mask_mode, dropout=None):
 
 
 def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode, need_dres,
-              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None, dropout=None, sink_scale=1.0):
+              gw_sink=None, gb_sink=None, lsdy=None, lsdyx=None, dropout=None, sink_scale=1.0, sum_replicas=None):
+    """``sum_replicas``: optional fp32 [R, 2, C] partial sums left by a data-gradient store loop
+    (ops._hip_conv.dgrad_bn_fused); ``sdy``/``sdyx`` (and ``lsdy``/``lsdyx``) must then be its first
+    replica — the kernel folds the R replicas itself, no sum kernel runs."""
     _check_act(x, "x")
     dy, ld = _strided(dy, "dy", x)
     M, C = _mc(x)
@@ -199,8 +203,16 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
     dres = torch.empty_like(x) if need_dres else None
     if (mask_mode == 3) != (dropout is not None):
         raise ValueError("mask_mode 3 <=> fused dropout")
+    if sum_replicas is not None:
+        r = sum_replicas
+        if r.dtype != torch.float32 or r.dim() != 3 or tuple(r.shape[1:]) != (2, C) or not r.is_contiguous() \
+                or sdy is None or sdy.data_ptr() != r.data_ptr() or sdyx.data_ptr() != r.data_ptr() + 4 * C \
+                or (lsdy is not None and (lsdy.data_ptr() != sdy.data_ptr() or lsdyx.data_ptr() != sdyx.data_ptr())):
+            raise ValueError("sum_replicas: contiguous fp32 [R, 2, C] whose first replica is (sdy, sdyx)")
     _arm_dropout(dropout)
     _arm_ld(ld, C)
+    if sum_replicas is not None and sum_replicas.shape[0] > 1:
+        B.check(_lib().dp_bn_set_sum_replicas(int(sum_replicas.shape[0]), 2 * C), "bn_set_sum_replicas")
     B.check(_lib().dp_bn_bwd_apply(B.ptr(dy), B.ptr(x), B.ptr(y if mask_mode == 1 else None), B.ptr(dx),
                                    B.ptr(dres), M, C, B.ptr(mean), B.ptr(invstd), B.ptr(weight), B.ptr(bias),
                                    B.ptr(sdy), B.ptr(sdyx), float(count), int(mask_mode), B.ptr(gw_sink),

@@ -117,7 +117,10 @@ _FORCED_CFG = int(os.environ["DPAMD_CONV_CFG"]) if "DPAMD_CONV_CFG" in os.enviro
 _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
 # 11-13 (32-wide K steps, 4-stage ring) are selectable but not tried: measured 8-10 % slower than their
 # 64-wide 2-stage counterparts on every R101 layer at batch 128 (profiles/r1_conv_cfg_sweep_b128.log)
-_CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 0)
+# 14-16: small-LDS tiles (3-4 resident blocks per CU) for short-K layers bound by their store loop: 16 wins 23
+# and 15 five of the 69 headline problems (gpurun_out/s90, s91: 944-952 img/s against 928 without them on the
+# same box).  17 / 18 (their 8-wave forms) were never picked in three tuning runs: selectable, not tried.
+_CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 14, 15, 16, 0)
 _TUNED: dict = {}
 
 
@@ -129,7 +132,7 @@ def _load_tuned(path: str) -> None:
 
 
 # Packaged table for the headline problem (DeepLabv3+ R101, 513², per-GPU batch 128 on MI355X): the
-# majority choice of three autotune runs (gpurun_out/s63).  Every rank then runs the SAME tiles from the
+# majority choice of three autotune runs (tools/merge_tune.py; gpurun_out/s91).  Every rank then runs the SAME tiles from the
 # first step — per-rank tuning noise flips near-ties (20 of 101 problems differed between runs), and under
 # data parallelism the slowest rank's choice gates every step.  Problems not in the table are measured as
 # before; DPAMD_CONV_TUNE_TABLE=0 ignores the table.
@@ -192,8 +195,9 @@ def tuned_table() -> dict:
 
 def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, dil, residual, holder, a=None):
     """Data gradient with the previous layer's BN+ReLU backward prologue fused into the store loop
-    (csrc/conv_igemm2.hip, Conv2Args::bnx): returns ``(dm, sdy, sdyx)`` — the ReLU-masked gradient and
-    the per-channel Σdm, Σdm·x̂ — or ``None`` when the second-generation kernel does not take the shape."""
+    (csrc/conv_igemm2.hip, Conv2Args::bnx): returns ``(dm, sums)`` — the ReLU-masked gradient and the
+    per-channel partial sums fp32 [reps, 2, Cout] of (Σdm, Σdm·x̂) — or ``None`` when the second-generation
+    kernel does not take the shape."""
     n, cin, hi, wi = dy.shape
     cout, cin_w, r, s = wt.shape
     ho, wo = out_hw
@@ -242,8 +246,7 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
     if st == -2:
         return None
     B.check(st, "conv_igemm2b")
-    red = sums[0] if reps == 1 else sums.sum(0)
-    return y, red[0], red[1]
+    return y, sums           # [reps, 2, Cout] partial sums: BN backward's apply kernel folds the replicas
 
 
 def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
@@ -439,8 +442,8 @@ class _ConvIGemm(torch.autograd.Function):
             if ctx.bn_holder is not None and cout_p == cout:
                 fused = dgrad_bn_fused(dy, wt, (hi, wi), stride[0], pad_t, dilation, dskip, ctx.bn_holder, x)
             if fused is not None:
-                dx, sdy, sdyx = fused
-                ctx.bn_holder["sums"] = (sdy, sdyx)
+                dx, part = fused
+                ctx.bn_holder["sums"] = part
                 ctx.bn_holder["dm_ptr"] = dx.data_ptr()
             else:
                 dx = igemm(dy, wt, (hi, wi), 1, stride[0], pad_t, dilation, residual=dskip)

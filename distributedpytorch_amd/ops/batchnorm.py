@@ -205,14 +205,20 @@ class _BatchNormActTrain(torch.autograd.Function):
         need_dres = ctx.has_res and ctx.needs_input_grad[3]
         mask_mode = ctx.mask_mode if ctx.hip else 0
         fused_dres = None
+        sum_reps = None
         if ctx.hip and need_dres and ctx.mask_mode == 0:
             fused_dres, need_dres = dy, False        # no activation: the residual's gradient IS dy (no copy)
         h = ctx.holder
         if ctx.hip and h is not None and h.get("dm_ptr") == dy.data_ptr() and h.get("sums") is not None:
             # the consumer's data-gradient kernel already applied the ReLU mask to dy and left the two
             # reductions behind: no bn_bwd_reduce pass, no mask source read, the residual gradient IS dy
-            sdy, sdyx = h["sums"]
+            part = h["sums"]                      # fp32 [reps, 2, C] partial sums
             h["sums"] = None
+            if part.shape[0] > 1 and not ctx.sync:
+                sum_reps = part                   # folded inside the apply kernel (no sum kernel)
+            elif part.shape[0] > 1:
+                part = part.sum(0, keepdim=True)  # SyncBN: one [2, C] message
+            sdy, sdyx = part[0, 0], part[0, 1]
             mask_mode = 0
             if need_dres:
                 fused_dres, need_dres = dy, False
@@ -251,7 +257,8 @@ class _BatchNormActTrain(torch.autograd.Function):
                 # affine gradients are added into the gradient arena by the same kernel
                 from . import _hip_bn
                 dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                             mask_mode, need_dres, gw, gb, sdy, sdyx, ctx.dropout, sink_scale)
+                                             mask_mode, need_dres, gw, gb, sdy, sdyx, ctx.dropout, sink_scale,
+                                             sum_replicas=sum_reps)
                 if fused_dres is not None:
                     dres = fused_dres
                 for prm in (wp, bp):
@@ -261,9 +268,12 @@ class _BatchNormActTrain(torch.autograd.Function):
                 return dx, None, None, dres, None, None, None, None, None, None, None, None, None, None
             from . import _hip_bn
             dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                         mask_mode, need_dres, dropout=ctx.dropout)
+                                         mask_mode, need_dres, dropout=ctx.dropout, sum_replicas=sum_reps)
             if fused_dres is not None:
                 dres = fused_dres
+            if sum_reps is not None:
+                red = sum_reps.sum(0)             # autograd-owned affine gradients below need the totals
+                sdy, sdyx = red[0], red[1]
         else:
             dx, dres = _t_bwd_apply(dy, x, y, mean, invstd, w, g_sdy, g_sdyx, ctx.count, ctx.relu, need_dres)
         # affine grads are *local* sums: DDP's gradient all-reduce averages them like any other param

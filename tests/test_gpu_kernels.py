@@ -142,7 +142,7 @@ IGEMM2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("case", IGEMM2_CASES)
 def test_igemm2_all_tile_configs(case, cfg):
     """csrc/conv_igemm2.hip: every tile configuration, forward + data-gradient + fused statistics,
@@ -598,13 +598,14 @@ def test_graphed_eval_forward_matches_eager():
                 p.mul_(0.97)
 
 
-@pytest.mark.parametrize("block_name", ["Bottleneck", "BasicBlock"])
-def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name):
+@pytest.mark.parametrize("block_name,hw", [("Bottleneck", (33, 31)), ("BasicBlock", (33, 31)), ("Bottleneck", (65, 67))])
+def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name, hw):
     """csrc/conv_igemm2.hip (Conv2Args::bnx): BN+ReLU backward's mask and reductions computed in the
     consumer's data-gradient store loop give the same parameter and input gradients as the separate
     bn_bwd_reduce pass.  One residual stage (projection block + 2 identity blocks) keeps the
     comparison well conditioned (a whole random-init ResNet at batch 2 is chaotic: two runs of the
-    SAME path differ by O(1) once the autotuner picks different tiles)."""
+    SAME path differ by O(1) once the autotuner picks different tiles).  The 65x67 case has enough rows
+    (17420) for the store loop to spread its sums over two replicas, which bn_bwd_apply folds."""
     from distributedpytorch_amd.models import resnet
     from distributedpytorch_amd.ops import _hip_conv
     block = getattr(resnet, block_name)
@@ -619,8 +620,8 @@ def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name):
             blocks = [block(cin, planes, 1, 1, resnet._Projection(cin, cout, 1)), block(cout, planes), block(cout, planes)]
             blocks[1].input_exclusive = blocks[2].input_exclusive = True
             net = torch.nn.Sequential(*blocks).to(DEV).to(memory_format=torch.channels_last).train()
-            x = _nhwc(_bf(torch.randn(4, cin, 33, 31, device=DEV))).requires_grad_(True)
-            t = _nhwc(_bf(torch.randn(4, cout, 33, 31, device=DEV)))
+            x = _nhwc(_bf(torch.randn(4, cin, *hw, device=DEV))).requires_grad_(True)
+            t = _nhwc(_bf(torch.randn(4, cout, *hw, device=DEV)))
             (net(x).float() - t.float()).pow(2).mean().backward()
             g = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
             g["input"] = x.grad.detach().float().clone()
@@ -633,6 +634,82 @@ def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name):
     # a wrong mask or a missing term shows up as O(1); rounding-order differences stay at a few percent
     assert worst < max(6e-2, 8 * noise), (worst, noise)
 
+
+@pytest.mark.parametrize("cfg", [1, 5, 9, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("k,with_res", [(1, True), (3, False)])
+def test_dgrad_bn_fused_store_loop_per_tile_config(cfg, k, with_res):
+    """csrc/conv_igemm2.hip, Conv2Args::bnx, for a forced tile configuration (the small-LDS tiles 14-18
+    included): masked gradient dm = (dgrad [+ skip])·[a > 0] and the partial sums Σdm, Σdm·x̂ against a
+    plain fp32 computation from an fp32 CPU transposed convolution."""
+    from distributedpytorch_amd.ops import _hip_conv
+    torch.manual_seed(5)
+    n, cin, cout, h, w = 3, 96, 160, 37, 29          # forward conv cin -> cout; its dgrad produces cin channels
+    pad = k // 2
+    wt = _bf(torch.randn(cout, cin, k, k, device=DEV) / math.sqrt(cin * k * k))
+    dy = _bf(torch.randn(n, cout, h, w, device=DEV))
+    bx = _bf(torch.randn(n, cin, h, w, device=DEV))                      # pre-BN activations of the producer
+    mean, invstd = torch.randn(cin, device=DEV) * 0.1, torch.rand(cin, device=DEV) + 0.5
+    gam, bet = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.2
+    res = _bf(torch.randn(n, cin, h, w, device=DEV)) if with_res else None
+    v = lambda t: t.view(1, -1, 1, 1)  # noqa: E731
+    pre = bx.float() * v(gam * invstd) + v(bet - mean * gam * invstd)
+    a = _bf(torch.relu(pre + (res.float() if with_res else 0)))          # the activation this conv consumed
+    da = torch.nn.grad.conv2d_input((n, cin, h, w), wt.float().cpu(), dy.float().cpu(), 1, pad, 1).to(DEV)
+    if with_res:
+        da = da + res.float()
+    mask = (a.float() > 0) if with_res else (pre > 0)
+    dm_ref = da * mask
+    holder = dict(x=_nhwc(bx), mask_from_a=with_res, mean=mean, invstd=invstd, w=gam, b=bet)
+    wT = _hip_conv.weight_transpose(_nhwc(wt))
+    old = _hip_conv._FORCED_CFG
+    _hip_conv._FORCED_CFG = cfg
+    try:
+        out = _hip_conv.dgrad_bn_fused(_nhwc(dy), wT, (h, w), 1, (pad, pad), (1, 1),
+                                       _nhwc(res) if with_res else None, holder, _nhwc(a) if with_res else None)
+    finally:
+        _hip_conv._FORCED_CFG = old
+    assert out is not None
+    dm, part = out
+    assert part.dim() == 3 and tuple(part.shape[1:]) == (2, cin)
+    assert _rel(dm, dm_ref) < 1.5e-2
+    dmf = dm.float()                                   # the sums are taken over the bf16-rounded dm
+    xhat = (bx.float() - v(mean)) * v(invstd)
+    sums = part.sum(0)
+    s1_ref, s2_ref = dmf.sum(dim=(0, 2, 3)), (dmf * xhat).sum(dim=(0, 2, 3))
+    scale = float(dmf.abs().sum(dim=(0, 2, 3)).max())
+    assert float((sums[0] - s1_ref).abs().max()) < 2e-3 * scale
+    assert float((sums[1] - s2_ref).abs().max()) < 4e-3 * scale
+
+
+@pytest.mark.parametrize("C", [64, 728])
+def test_bn_bwd_apply_folds_sum_replicas(C):
+    """csrc/bn_relu.hip bn_bwd_apply_kernel: the [R, 2, C] partial sums a data-gradient store loop leaves
+    behind (large maps spread their atomics over R replicas) are folded inside the kernel — same dx and
+    same affine-gradient sinks as with the replicas summed beforehand by a separate kernel."""
+    from distributedpytorch_amd.ops import _hip_bn
+    torch.manual_seed(3)
+    n, h, w, R = 2, 19, 23, 5
+    x = _nhwc(_bf(torch.randn(n, C, h, w, device=DEV)))
+    dy = _nhwc(_bf(torch.randn(n, C, h, w, device=DEV)))
+    mean, invstd = torch.randn(C, device=DEV) * 0.1, torch.rand(C, device=DEV) + 0.5
+    wgt, bias = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    part = torch.randn(R, 2, C, device=DEV)
+    red = part.sum(0)
+    count = float(n * h * w)
+    gw0, gb0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gw1, gb1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ref, _ = _hip_bn.bwd_apply(dy, x, None, mean, invstd, wgt, bias, red[0], red[1], count, 0, False,
+                               gw0, gb0, red[0], red[1])
+    got, _ = _hip_bn.bwd_apply(dy, x, None, mean, invstd, wgt, bias, part[0, 0], part[0, 1], count, 0, False,
+                               gw1, gb1, part[0, 0], part[0, 1], sum_replicas=part)
+    assert _rel(got.float(), ref.float()) < 1e-2
+    assert torch.allclose(gw1, red[1], atol=1e-5) and torch.allclose(gb1, red[0], atol=1e-5)
+    assert torch.allclose(gw1, gw0, atol=1e-5) and torch.allclose(gb1, gb0, atol=1e-5)
+    # the replica state is per launch: the next call reads plain [C] sums again
+    again, _ = _hip_bn.bwd_apply(dy, x, None, mean, invstd, wgt, bias, red[0], red[1], count, 0, False)
+    assert torch.equal(again, ref)
+    with pytest.raises(ValueError):
+        _hip_bn.bwd_apply(dy, x, None, mean, invstd, wgt, bias, red[0], red[1], count, 0, False, sum_replicas=part)
 
 
 
