@@ -237,11 +237,18 @@ __device__ __forceinline__ void lds_dma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // A K-step then moves 48 KiB for 256x128x64 MACs instead of 2 x 32 KiB: the kernel is bound by the
 // L2->LDS stream (README, "Where the time goes"), and the weight gradients cost the critical path 26 ms
 // of a 146 ms step even on their own stream (gpurun_out/s66: 120 ms without them).
-template <bool UNIT, int G>
-__global__ __launch_bounds__(kThreads * G, 2) void conv_wgrad2_kernel(Wgrad2Args p) {
+//
+// NST = 3 (G = 2 only: 3 x 48 KiB of the 160 KiB LDS, one block per CU): a three-deep ring.  With two stages
+// one block has a single 48 KiB stage in flight while it computes — at one block per CU that is all the CU
+// has outstanding, far below what the L2->LDS stream needs to cover its latency; the third stage keeps TWO
+// stages (96 KiB) in flight across every barrier (counted vmcnt, the stage issued last stays outstanding).
+template <bool UNIT, int G, int NST = 2>
+__global__ __launch_bounds__(kThreads * G, NST == 3 ? 1 : 2) void conv_wgrad2_kernel(Wgrad2Args p) {
     constexpr int XOFF = G * TILE_BYTES;                 // x tile offset inside a stage
     constexpr int STG = (G + 1) * TILE_BYTES;            // bytes per stage
     constexpr int NR = 4 / G;                            // x load rounds per thread (16*G rows each)
+    constexpr int LPS = 4 + NR;                          // LDS-DMA instructions per thread per stage
+    static_assert(NST == 2 || NST == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -404,14 +411,20 @@ __global__ __launch_bounds__(kThreads * G, 2) void conv_wgrad2_kernel(Wgrad2Args
                                                               __builtin_bit_cast(bf16x8, vb), acc[i_][j_], 0, 0, 0); \
     }
 
-    unsigned flip = (unsigned)STG;
     if (nsteps > 0) issue_stage(0);
+    if (NST == 3 && nsteps > 1) issue_stage(1);
+    int cur = 0;                                        // ring slot of step t (uniform)
     for (int t = 0; t < nsteps; ++t) {
-        // stage t landed (vmcnt) and my reads of the other buffer are done (every read is waited for
-        // before the MFMAs that close a step), then everyone's
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage t landed (vmcnt) and my reads of the slot refilled below are done (every read is waited
+        // for before the MFMAs that close a step), then everyone's
+        if (NST == 3 && t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < nsteps) issue_stage((t & 1) ^ 1);
+        if (NST == 3) {
+            if (t + 2 < nsteps) issue_stage(cur == 0 ? 2 : cur - 1);      // (cur + 2) % 3: the slot read in step t-1
+        } else {
+            if (t + 1 < nsteps) issue_stage(cur ^ 1);
+        }
         WG2_READS(0, 0)
         WG2_READS(1, 1)
         WG2_WAIT(0, 8);
@@ -424,12 +437,14 @@ __global__ __launch_bounds__(kThreads * G, 2) void conv_wgrad2_kernel(Wgrad2Args
         WG2_MFMA(0)
         WG2_WAIT(1, 0);
         WG2_MFMA(1)
-        // flip the fragment addresses to the other buffer
+        // move the fragment addresses to the next ring slot
+        const bool wrap = cur == NST - 1;
+        const unsigned step = wrap ? 0u - (unsigned)((NST - 1) * STG) : (unsigned)STG;
+        cur = wrap ? 0 : cur + 1;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) { aA[a][b] += flip; aB[a][b] += flip; }
-        flip = 0u - flip;
+            for (int b = 0; b < 2; ++b) { aA[a][b] += step; aB[a][b] += step; }
     }
 #undef WG2_READS
 #undef WG2_WAIT
@@ -530,6 +545,19 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     q.dil_h = dil_h; q.dil_w = dil_w; q.NF = p.NF; q.tiles_k = p.tiles_k; q.tiles_n = p.tiles_n; q.splits = p.splits;
     q.px_per_split = p.px_per_split; q.x_bytes = (unsigned)x_bytes; q.ldx = ldx;
     const bool unit = R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1 && ldx == Cin;
+    static const int ring = getenv("DPAMD_WGRAD_RING") ? atoi(getenv("DPAMD_WGRAD_RING")) : 3;
+    if (G == 2 && ring == 3) {
+        constexpr int lds3 = 3 * 3 * TILE_BYTES;      // 144 KiB: three stages, one block per CU
+        static bool once3 = false;
+        if (!once3) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+            once3 = true;
+        }
+        if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 2, 3>), dim3((unsigned)nwg), dim3(2 * kThreads), lds3, st, q);
+        else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2, 3>), dim3((unsigned)nwg), dim3(2 * kThreads), lds3, st, q);
+        return DP_LAUNCH_STATUS();
+    }
     if (G == 2) {
         constexpr int lds2 = 2 * 3 * TILE_BYTES;      // 96 KiB
         static bool once = false;

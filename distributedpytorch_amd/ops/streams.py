@@ -26,6 +26,33 @@ _ENABLED = os.environ.get("DPAMD_AUX_STREAM", "1") != "0"
 # drained, a kernel of another stream can.  Measured at B32 (gpurun_out/s8_bench_b32_aux*.log): 697 img/s
 # with one aux stream, 685 with two, so one is the default; GPU_MAX_HW_QUEUES is 4 (main + comm + 2 aux).
 _NAUX = max(1, int(os.environ.get("DPAMD_AUX_STREAMS", "1")))
+# Queue priority of the auxiliary stream(s).  "low": created with hipStreamCreateWithPriority at the LEAST
+# priority of the device's range, so when both hardware queues hold ready workgroups the dgrad -> BN-backward
+# chain (the critical path, on the normal-priority current stream) is dispatched first and the weight
+# gradients fill the CUs it leaves free instead of taking half of them.  torch.cuda.Stream only reaches the
+# normal and high levels, hence the direct runtime call + torch.cuda.ExternalStream.
+_PRIORITY = os.environ.get("DPAMD_AUX_PRIORITY", "low")
+_raw_handles: list = []     # keeps the hipStream_t of the external streams (never destroyed: process lifetime)
+
+
+def _make_stream(idx: int) -> "torch.cuda.Stream":
+    if _PRIORITY == "low":
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+            with torch.cuda.device(idx):
+                if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0 \
+                        and least.value > greatest.value:
+                    handle = ctypes.c_void_p()
+                    # flags = 1: hipStreamNonBlocking (no implicit ordering against the null stream)
+                    if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), least) == 0 \
+                            and handle.value:
+                        _raw_handles.append(handle)
+                        return torch.cuda.ExternalStream(handle.value, device=idx)
+        except OSError:
+            pass
+    return torch.cuda.Stream(device=idx)
 _streams: Dict[int, list] = {}
 _next: Dict[int, int] = {}
 _dirty: Dict[int, bool] = {}
@@ -45,7 +72,7 @@ def aux_stream(device: Optional[torch.device] = None) -> "torch.cuda.Stream":
     idx = torch.cuda.current_device() if device is None or device.index is None else device.index
     pool = _streams.get(idx)
     if pool is None:
-        pool = _streams[idx] = [torch.cuda.Stream(device=idx) for _ in range(_NAUX)]
+        pool = _streams[idx] = [_make_stream(idx) for _ in range(_NAUX)]
         _next[idx] = 0
     k = _next[idx]
     _next[idx] = (k + 1) % len(pool)

@@ -14,6 +14,8 @@ The loss is returned as a device tensor; callers decide when to pay for a host r
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Iterable, Optional, Sequence
 
 import torch
@@ -61,6 +63,15 @@ class TrainEngine:
         self.timer = PhaseTimer(self.on_gpu, markers)
         self.global_step = 0
         self._step_events: list = []      # bounds how far the host may run ahead of the GPU
+        # The weight gradients run on a LOW-priority stream (ops.streams): when both hardware queues hold ready
+        # workgroups the forward / dgrad -> BN-backward chain is dispatched first.  Measured at B128
+        # (gpurun_out/s94, s95): 951 img/s with equal priorities, 957-958 with the low-priority auxiliary stream.
+        # DPAMD_MAIN_PRIORITY=high additionally runs the step itself on a HIGH-priority stream (961-962 on one
+        # GPU).  Not the default: RCCL's kernels run at normal priority and would be dispatched behind every
+        # compute kernel, and two ranks SHARING one GPU (the rehearsal of tests/test_gpu_p2p.py) stalled with it.
+        self._main = None
+        if self.on_gpu and os.environ.get("DPAMD_MAIN_PRIORITY", "normal") == "high":
+            self._main = torch.cuda.Stream(device=self.device, priority=-1)
 
     # ------------------------------------------------------------------
     def prepare_input(self, images: torch.Tensor) -> torch.Tensor:
@@ -72,6 +83,22 @@ class TrainEngine:
         return x
 
     def train_step(self, images: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if self._main is None:
+            return self._train_step(images, target)
+        outer = torch.cuda.current_stream(self.device)
+        if outer == self._main:
+            return self._train_step(images, target)
+        self._main.wait_stream(outer)                  # the batch (augmentation, copies) is ready
+        with torch.cuda.stream(self._main):
+            loss = self._train_step(images, target)
+        for t in (images, target):
+            if t.is_cuda:
+                t.record_stream(self._main)            # allocated on ``outer``, read on the step's stream
+        outer.wait_stream(self._main)                  # whatever the caller queues next sees the updated weights
+        loss.record_stream(outer)
+        return loss
+
+    def _train_step(self, images: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         self.model.train()
         x = self.prepare_input(images)
         # TODO `train_pascal.py:5`: "label non_blocking = True"
