@@ -200,8 +200,35 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         }
     }
 
+    // ---- taps that are padding for EVERY pixel of this tile are not iterated at all ----
+    // A dilated 3x3 on a 33x33 map (ASPP, dilation 12 / 18) has whole bands of rows for which the taps
+    // one dilation above (or below) fall outside the image: a 192-pixel tile is ~6 image rows, so for
+    // those tiles three of the nine taps would be K-steps of zeros (DMA of out-of-range lanes, MFMAs on
+    // zeros).  tile_mask = OR of the per-row validity masks; the iterator below walks its set bits only.
+    unsigned tile_mask = 0xffffffffu;
+    int ksteps = p.ksteps;
+    if (!UNIT) {
+        unsigned mk = 0;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) mk |= a_mask[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mk |= (unsigned)__shfl_xor((int)mk, off, 64);
+        unsigned* sm = reinterpret_cast<unsigned*>(smem);
+        if (lane == 0) sm[wave] = mk;
+        __syncthreads();
+        unsigned all = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < T / 64; ++w2) all |= sm[w2];
+        tile_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)all);
+        __syncthreads();                                   // smem is about to receive the first stages
+        ksteps = __builtin_popcount(tile_mask) * p.csteps;
+    }
+
     // ---- K-step iterator of the ISSUE side (uniform): filter tap (kr, ks), 64-channel slice kc ----
     int kr = 0, ks = 0, kc = 0;
+    if (!UNIT) {
+        while (kr < p.R && !((tile_mask >> (kr * p.S + ks)) & 1u)) { if (++ks == p.S) { ks = 0; ++kr; } }
+    }
     const int sdr = (1 << p.sdl) - 1;
     auto issue_stage = [&](int buf) {
         unsigned char* abase = smem + buf * STAGE + wave * 1024;       // one wave-instruction fills 1 KiB
@@ -231,7 +258,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) lds_dma16(rw, bbase + i * (RPR * ROWB), b_voff[i], w_soff);
-        if (++kc == p.csteps) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+        if (++kc == p.csteps) {
+            kc = 0;
+            do { if (++ks == p.S) { ks = 0; ++kr; } } while (!UNIT && kr < p.R && !((tile_mask >> (kr * p.S + ks)) & 1u));
+        }
     };
 
     // ---- accumulators: acc[mi][ni][j] = out(pixel tile mi, lane&15 ; channel tile ni, (lane>>4)*4 + j) ----
@@ -249,7 +279,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     const int ch0 = ((q ^ fsw) << 4), ch1 = (((4 + q) ^ fsw) << 4);      // ch1: second half of a 64-wide step
 
     // ---- prologue: NST-1 stages in flight ----
-    const int ksteps = p.ksteps;
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s < ksteps) issue_stage(s);
