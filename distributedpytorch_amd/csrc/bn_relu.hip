@@ -89,24 +89,18 @@ __device__ __forceinline__ void block_reduce_atomic(const Map& m, float (&acc)[N
         }
         return;
     }
-    // generic path (ragged last slab): smem layout [NACC][kThreads]
+    // generic path (ragged last slab): smem layout [NACC][kThreads]; one thread per (statistic, channel)
+    // folds the row lanes (the first version left all NACC x rpp additions to cgs threads: 672 serial LDS
+    // reads per block for the decoder's 48-channel layer, 375 us for a 400 MB reduction)
 #pragma unroll
     for (int j = 0; j < NACC; ++j) smem[j * kThreads + threadIdx.x] = m.active ? acc[j] : 0.f;
     __syncthreads();
-    if (m.rlane == 0 && threadIdx.x < m.cgs) {
-        const int cgl = threadIdx.x;  // == cg - base because rlane == 0
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-            float s = 0.f;
-            for (int rl = 0; rl < m.rpp; ++rl) s += smem[j * kThreads + rl * m.cgs + cgl];
-            acc[j] = s;
-        }
-        const int c0 = m.cg * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(out0 + c0 + j, acc[j]);
-            atomicAdd(out1 + c0 + j, acc[8 + j]);
-        }
+    if ((int)threadIdx.x < NACC * m.cgs) {
+        const int j = threadIdx.x / m.cgs, cgl = threadIdx.x - j * m.cgs;
+        float s = 0.f;
+        for (int rl = 0; rl < m.rpp; ++rl) s += smem[j * kThreads + rl * m.cgs + cgl];
+        const int c = (blockIdx.y * kReduceSlab + cgl) * 8 + (j & 7);
+        atomicAdd((j < 8 ? out0 : out1) + c, s);
     }
 }
 
