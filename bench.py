@@ -123,6 +123,11 @@ def main():
                        "parallelism": f"dp{world}", "impl": args.impl, "sync_bn": bool(args.sync_bn),
                        "optimizer": "sgd-momentum", "final_loss": round(final_loss, 4)},
         }
+        if args.model == "deeplabv3plus_resnet101" and args.crop == 513 and args.impl == "native" and on_gpu:
+            # the reference publishes nothing (vs_baseline stays null); the self-established baseline
+            # is the stock PyTorch-ROCm op path on the same model code (profiles/r1_stock_b32_bench.log, one MI355X)
+            rec["self_baseline"] = {"stock_pytorch_rocm_images_per_sec_per_gpu": 251.8,
+                                    "ratio_per_gpu": round(ips / world / 251.8, 3)}
         print(json.dumps(rec), flush=True)
     dist_env.shutdown()
 
