@@ -113,12 +113,24 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_raw* __rest
                                                           bf16_raw* __restrict__ dx, Pool p) {
     const int C8 = p.C >> 3;
     const long total = (long)p.N * p.Hi * p.Wi * C8;
+    const bool small = total <= 0x7fffffffL;     // 32-bit index arithmetic (64-bit div/mod: ~100 VALU each)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % C8);
-        long pix = i / C8;
-        const int ix = (int)(pix % p.Wi); pix /= p.Wi;
-        const int iy = (int)(pix % p.Hi);
-        const int n = (int)(pix / p.Hi);
+        int cg, ix, iy, n;
+        if (small) {
+            const unsigned u = (unsigned)i;
+            const unsigned pix = u / (unsigned)C8;
+            cg = (int)(u - pix * (unsigned)C8);
+            const unsigned row = pix / (unsigned)p.Wi;
+            ix = (int)(pix - row * (unsigned)p.Wi);
+            n = (int)(row / (unsigned)p.Hi);
+            iy = (int)(row - (unsigned)n * (unsigned)p.Hi);
+        } else {
+            cg = (int)(i % C8);
+            long pix = i / C8;
+            ix = (int)(pix % p.Wi); pix /= p.Wi;
+            iy = (int)(pix % p.Hi);
+            n = (int)(pix / p.Hi);
+        }
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
