@@ -1,10 +1,17 @@
 #!/usr/bin/env python
 """Headline benchmark: training images/sec of DeepLabv3+ ResNet-101 at 513×513, bf16, synthetic
 VOC-shaped data (21 classes + ignore 255), random-init weights — the metric/config named in
-BASELINE.json.  One process per GPU; for N>1 launch with
+BASELINE.json.  One process per GPU over RCCL/xGMI:
 
+    python bench.py --gpus N --steps K --warmup W        # self-launching: starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # same, under torchrun
+
+(the reference drives its GPUs from ONE command too, `/root/reference/train_pascal.py:92`).  With
+``--gpus N > 1`` and no ``WORLD_SIZE`` in the environment the parent — before any GPU call — starts
+N fresh rank processes (parallel.launch) and exits with their status; rank 0 prints the ONE JSON line.
+Multi-rank GPU jobs need ``HSA_ENABLE_IPC_MODE_LEGACY=0`` in the environment before the first HIP
+call (dmabuf IPC); the launcher exports it, and ``init_distributed`` refuses to run without it.
 
 Each timed step is the full training step: GPU augmentation (random scale/crop/flip + normalise)
 of a device-resident uint8 batch → forward → fused ignore-index CE → backward with overlapped
@@ -12,7 +19,8 @@ bucketed gradient all-reduce → fused SGD.  Weak scaling: per-GPU batch is fixe
 
 ``--impl stock`` measures the stock PyTorch-ROCm path (MIOpen conv / ATen BN) on the same model
 code — the self-established baseline of BASELINE.md; ``--impl native`` (default) runs the
-hand-written HIP kernels.
+hand-written HIP kernels.  The stock numbers live in ``profiles/self_baseline.json`` (written by
+``--record-baseline``); the ratio reported beside the (null) ``vs_baseline`` is EQUAL-BATCH.
 """
 from __future__ import annotations
 
@@ -22,10 +30,9 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+BASELINE_FILE = os.path.join(ROOT, "profiles", "self_baseline.json")
 
 
 def parse_args():
@@ -37,36 +44,81 @@ def parse_args():
                     help="per-GPU batch (128 x 513² holds 55 GiB of the 288 GB HBM3E)")
     ap.add_argument("--crop", type=int, default=513)
     ap.add_argument("--model", default="deeplabv3plus_resnet101")
+    ap.add_argument("--in-channels", type=int, default=3)
     ap.add_argument("--output-stride", type=int, default=None)
     ap.add_argument("--impl", choices=["native", "stock"], default=os.environ.get("DPAMD_BENCH_IMPL", "native"))
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU/gloo (tiny shapes)")
     ap.add_argument("--phases", action="store_true", help="print per-phase HIP-event timings (rank 0)")
+    ap.add_argument("--record-baseline", action="store_true",
+                    help="with --impl stock: store this run in profiles/self_baseline.json")
+    ap.add_argument("--source-log", default=None, help="log file name recorded with --record-baseline")
     return ap.parse_args()
+
+
+def _baseline_key(model: str, crop: int) -> str:
+    return f"{model}@{crop}"
+
+
+def load_self_baseline(model: str, crop: int, batch: int):
+    """Equal-batch stock-op record {batch, img_s, source_log, ...} or None (no literals in this file)."""
+    try:
+        with open(BASELINE_FILE) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return table.get(_baseline_key(model, crop), {}).get(str(batch))
+
+
+def record_self_baseline(model: str, crop: int, batch: int, rec: dict) -> None:
+    try:
+        with open(BASELINE_FILE) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        table = {}
+    table.setdefault(_baseline_key(model, crop), {})[str(batch)] = rec
+    os.makedirs(os.path.dirname(BASELINE_FILE), exist_ok=True)
+    tmp = BASELINE_FILE + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    os.replace(tmp, BASELINE_FILE)
 
 
 def main():
     args = parse_args()
+    # ---- one command, N GPUs: the parent launches the ranks BEFORE anything touches the GPU ----
+    from distributedpytorch_amd.parallel.launch import maybe_self_launch
+    status = maybe_self_launch(args.gpus, cpu=args.cpu)
+    if status is not None:
+        sys.exit(status)
+
     # hang watchdog (SURVEY.md §5.3): DPAMD_HANG_DUMP_S=N dumps every thread's Python stack to stderr
     # and exits if the run is still going after N seconds — a stuck collective names its call site
     if os.environ.get("DPAMD_HANG_DUMP_S"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DPAMD_HANG_DUMP_S"]), exit=True)
+    import numpy as np
+    import torch
     from distributedpytorch_amd import ops
     from distributedpytorch_amd.models import build_model
     from distributedpytorch_amd.ops import SoftmaxCrossEntropy, affine_augment, make_affine_params
     from distributedpytorch_amd.parallel import TrainEngine, dist_env, init_distributed
 
     info = init_distributed(device="cpu" if args.cpu else None)
-    if info.world_size != args.gpus and info.is_master:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={info.world_size}; using WORLD_SIZE",
-              file=sys.stderr)
+    if info.world_size != args.gpus:
+        # never report a job of a different size under the requested label
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the job has WORLD_SIZE={info.world_size}")
     on_gpu = info.device.type == "cuda"
     if args.impl == "stock":
         ops.set_backend("torch")
+    elif ops.get_backend() != "auto":
+        raise SystemExit(f"[bench] --impl native but DPAMD_BACKEND={ops.get_backend()!r} forces the PyTorch ops; "
+                         "unset it or pass --impl stock")
     torch.manual_seed(1234)  # identical init on every rank; DDP broadcasts anyway
-    model = build_model(args.model, 21, output_stride=args.output_stride, sync_bn=args.sync_bn)
+    nclass = 21
+    model = build_model(args.model, nclass, output_stride=args.output_stride, sync_bn=args.sync_bn,
+                        in_channels=args.in_channels)
     engine = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.007, momentum=0.9, weight_decay=5e-4,
                          device=info.device, bucket_mb=args.bucket_mb)
     B, S = args.batch, args.crop
@@ -78,12 +130,17 @@ def main():
     lab[:, : S // 32] = 255
     raw_lab = lab.to(info.device)
     rng = np.random.default_rng(7 + info.rank)
+    extra_ch = None
+    if args.in_channels > 3:        # RGB + guidance channels (the instance task's 4-channel input)
+        extra_ch = torch.rand(B, args.in_channels - 3, S, S, generator=g).to(info.device)
 
     def one_step():
         mats = make_affine_params(B, (S, S), (S, S), scales=(0.5, 2.0), flip_p=0.5, rng=rng)
         with engine.timer.phase("augment"):
             x, y = affine_augment(raw_img, raw_lab, torch.from_numpy(mats).to(info.device, non_blocking=True),
                                   (S, S), out_dtype=engine.compute_dtype)
+            if extra_ch is not None:
+                x = torch.cat([x, extra_ch.to(x.dtype)], dim=1).contiguous(memory_format=torch.channels_last)
         return engine.train_step(x, y)
 
     def sync():
@@ -102,32 +159,60 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = dist_env.all_reduce_scalar(elapsed, "max", info.device if on_gpu else None)
     final_loss = float(loss.item())
+    phases = engine.timer.summary()
+    # exposed communication = what the step's stream waited for in finish_gradient_sync (HIP events), worst rank
+    comm_wait = dist_env.all_reduce_scalar(phases.get("comm_wait", 0.0), "max", info.device if on_gpu else None)
+    devices = [info.device.index if on_gpu else -1]
+    if info.world_size > 1:
+        import torch.distributed as dist
+        gathered = [None] * info.world_size
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
     world = info.world_size
     ips = world * B * args.steps / elapsed
     if info.is_master:
         if args.phases:
-            print("[bench] phases(ms):", {k: round(v, 3) for k, v in engine.timer.summary().items()},
-                  file=sys.stderr)
+            print("[bench] phases(ms):", {k: round(v, 3) for k, v in phases.items()}, file=sys.stderr)
             if on_gpu:
                 print(f"[bench] peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
+        headline = args.model == "deeplabv3plus_resnet101" and args.crop == 513 and args.in_channels == 3
         rec = {
-            "metric": ("train images/sec (node) DeepLabv3+ R101 513x513"
-                   if (args.model == "deeplabv3plus_resnet101" and args.crop == 513)
-                   else f"train images/sec (node) {args.model} {args.crop}x{args.crop}"),
+            "metric": ("train images/sec (node) DeepLabv3+ R101 513x513" if headline
+                       else f"train images/sec (node) {args.model} {args.crop}x{args.crop}"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if on_gpu else "fp32", "data": "synthetic",
             "config": {"model": args.model, "global_batch": world * B, "per_gpu_batch": B,
-                       "seq_len": S, "crop": S, "num_classes": 21,
+                       "seq_len": S, "crop": S, "num_classes": nclass, "in_channels": args.in_channels,
                        "parallelism": f"dp{world}", "impl": args.impl, "sync_bn": bool(args.sync_bn),
                        "optimizer": "sgd-momentum", "final_loss": round(final_loss, 4)},
+            "comm": {"backend": info.backend, "rccl_world": world if info.backend == "nccl" else 0,
+                     "devices": devices, "buckets": len(engine.ddp.arena.buckets), "bucket_mb": args.bucket_mb,
+                     "ddp_mode": engine.ddp.mode, "comm_wait_ms": round(comm_wait, 3),
+                     "exposed_comm_ms": round(comm_wait, 3)},
+            "runtime": {"ops_backend": ops.get_backend()},
         }
-        if args.model == "deeplabv3plus_resnet101" and args.crop == 513 and args.impl == "native" and on_gpu:
-            # the reference publishes nothing (vs_baseline stays null); the self-established baseline
-            # is the stock PyTorch-ROCm op path on the same model code (profiles/r1_stock_b32_bench.log, one MI355X)
-            rec["self_baseline"] = {"stock_pytorch_rocm_images_per_sec_per_gpu": 251.8,
-                                    "ratio_per_gpu": round(ips / world / 251.8, 3)}
+        if on_gpu and args.impl == "native":
+            from distributedpytorch_amd.ops import _backend, _hip_conv
+            bi = _backend.build_info()
+            tr = _hip_conv.tune_report()
+            rec["runtime"].update(lib_hash=bi.get("lib_hash"), lib_matches_sources=bi.get("lib_hash") == bi.get("source_hash"),
+                                  lib_rebuilt_at_load=bi.get("rebuilt"), tile_table_entries=tr["packaged"],
+                                  tiles_autotuned_in_run=tr["measured_here"],
+                                  tile_table_hit=tr["measured_here"] == 0)
+        if on_gpu:
+            base = load_self_baseline(args.model, S, B)
+            if args.impl == "native" and base is not None:
+                # the reference publishes nothing (vs_baseline stays null); the self-established
+                # baseline is the stock PyTorch-ROCm op path, same model code, same GPU type, SAME per-GPU batch
+                rec["self_baseline"] = dict(base, ratio_per_gpu_equal_batch=round(ips / world / base["img_s"], 3))
+            if args.impl == "stock" and args.record_baseline and world == 1:
+                record_self_baseline(args.model, S, B, {
+                    "batch": B, "img_s": round(ips, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+                    "steps": args.steps, "warmup": args.warmup, "source_log": args.source_log,
+                    "note": "stock PyTorch-ROCm ops (MIOpen conv, ATen BN/CE, full-resolution logits + ATen "
+                            "bilinear upsample), same model code, 1 x MI355X"})
         print(json.dumps(rec), flush=True)
     dist_env.shutdown()
 

@@ -11,6 +11,12 @@ Layer map (see SURVEY.md §1 for the reference's logical layers):
                 losses, mIoU / Jaccard metrics, JSONL logging, HIP-event timers
 """
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+import os as _os
+
+# dmabuf IPC is the only IPC mode of this platform's host driver; ROCr reads the variable once, at the first
+# HIP call, so it has to be in the environment before anything initialises the GPU (parallel.dist_env checks).
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from . import ops  # noqa: F401

@@ -2,7 +2,9 @@
 from . import workspace  # noqa: F401
 from ._backend import (NativeLibraryMissing, backend, get_backend, lib_built, set_backend,  # noqa: F401
                        use_hip)
-from .augment import IMAGENET_MEAN, IMAGENET_STD, affine_augment, make_affine_params  # noqa: F401
+from .augment import (IMAGENET_MEAN, IMAGENET_STD, affine_augment, affine_augment2, compose_crop,  # noqa: F401
+                      extreme_points, instance_augment, make_affine_params, make_warp_params, mask_bbox,
+                      nellipse_guidance_)
 from .batchnorm import (BatchNorm2d, batch_norm_act, convert_sync_batchnorm,  # noqa: F401
                         freeze_batchnorm)
 from .conv import Conv2d, conv2d, conv_bn_act, conv_out_size  # noqa: F401

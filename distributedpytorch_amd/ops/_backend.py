@@ -65,16 +65,46 @@ def use_hip(t: torch.Tensor) -> bool:
     return t.is_cuda and _mode != "torch"
 
 
+_build_info: dict = {}
+
+
+def _ensure_current() -> None:
+    """Missing or stale ``libdpamd_hip.so`` (its embedded source hash differs from the ``*.hip`` / ``common.h``
+    beside it): rebuild in-tree when ``DPAMD_AUTO_BUILD`` allows (default) and hipcc exists, else refuse.  A
+    stale library is never loaded silently — kernels and their Python launchers change together."""
+    from ..csrc import build as _b
+    want, have = _b.source_hash(), _b.embedded_hash(LIB_PATH)
+    _build_info.update(source_hash=want, lib_hash=have, rebuilt=False)
+    if have == want:
+        return
+    why = "not found" if not os.path.isfile(LIB_PATH) else f"stale (built from {have or 'unknown sources'}, tree is {want})"
+    if os.environ.get("DPAMD_AUTO_BUILD", "1") == "0" or not os.path.isfile(_b.HIPCC):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} {why}: run `python -m distributedpytorch_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950) before using the GPU path")
+    import sys
+    print(f"[dpamd] {LIB_PATH} {why}: building in-tree (hipcc --offload-arch=gfx950) ...", file=sys.stderr, flush=True)
+    _b.build_all(verbose=False)
+    _build_info.update(lib_hash=_b.embedded_hash(LIB_PATH), rebuilt=True)
+    if _build_info["lib_hash"] != want:
+        raise NativeLibraryMissing(f"{LIB_PATH}: rebuild did not produce a library matching the sources")
+
+
+def build_info() -> dict:
+    """{'source_hash', 'lib_hash', 'rebuilt'} of the loaded kernel library (bench reports, logs)."""
+    if not _build_info:
+        from ..csrc import build as _b
+        _build_info.update(source_hash=_b.source_hash(), lib_hash=_b.embedded_hash(LIB_PATH), rebuilt=False)
+    return dict(_build_info)
+
+
 def lib() -> ctypes.CDLL:
-    """The device-kernel library.  Raises loudly when it has not been built."""
+    """The device-kernel library.  Builds it when missing/stale, raises loudly when it cannot."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
-                if not os.path.isfile(LIB_PATH):
-                    raise NativeLibraryMissing(
-                        f"{LIB_PATH} not found: run `python -m distributedpytorch_amd.csrc.build` "
-                        "(hipcc --offload-arch=gfx950) before using the GPU path")
+                _ensure_current()
                 _lib = ctypes.CDLL(LIB_PATH)
     return _lib
 
@@ -91,6 +121,11 @@ def host_lib() -> ctypes.CDLL | None:
 
 def lib_built() -> bool:
     return os.path.isfile(LIB_PATH)
+
+
+def lib_current() -> bool:
+    from ..csrc import build as _b
+    return _b.is_current()
 
 
 def stream_ptr() -> ctypes.c_void_p:

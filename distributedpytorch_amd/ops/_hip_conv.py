@@ -122,6 +122,7 @@ _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
 # same box).  17 / 18 (their 8-wave forms) were never picked in three tuning runs: selectable, not tried.
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 14, 15, 16, 0)
 _TUNED: dict = {}
+_TUNE_COUNTS = {"packaged": 0, "measured_here": 0}
 
 
 def _load_tuned(path: str) -> None:
@@ -139,6 +140,7 @@ def _load_tuned(path: str) -> None:
 _TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 if os.environ.get("DPAMD_CONV_TUNE_TABLE", "1") != "0" and os.path.isfile(_TABLE):
     _load_tuned(_TABLE)
+    _TUNE_COUNTS["packaged"] = len(_TUNED)
 # optional cross-process cache of the measured choices (JSON): set DPAMD_CONV_TUNE_FILE
 _TUNE_FILE = os.environ.get("DPAMD_CONV_TUNE_FILE")
 if _TUNE_FILE and os.path.isfile(_TUNE_FILE):
@@ -154,7 +156,15 @@ def _save_tuned() -> None:
         os.replace(tmp, _TUNE_FILE)
 
 
+def tune_report() -> dict:
+    """How the tile configurations of this process were decided: ``packaged`` = entries of the shipped table
+    (ops/tuned_gfx950.json) at import, ``measured_here`` = problems autotuned in this process (0 means every
+    problem hit the table: all ranks run identical tiles from the first step)."""
+    return dict(_TUNE_COUNTS, entries=len(_TUNED), autotune=_AUTOTUNE, forced_cfg=_FORCED_CFG)
+
+
 def _autotune(args, stats, reps, cout, device, runner=None, candidates=None) -> int:
+    _TUNE_COUNTS["measured_here"] += 1
     lib = _lib()
     stream = B.stream_ptr()
     a = list(args)
@@ -325,6 +335,7 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil, runner=None) -> int:
     blocks, 81 us at 576), so the cost model's choice (0) competes with counts that land on
     0.5 / 0.75 / 1 / 1.5 / 2 / 3 rounds of blocks."""
     n, hi, wi, cin, ho, wo, cout, r, s = geom
+    _TUNE_COUNTS["measured_here"] += 1
     lib, stream = _lib(), B.stream_ptr()
     # blocks own 256 output channels when Cout fills them (csrc/conv_wgrad.hip, G = 2), else 128
     tk = 256 if (cout % 256 == 0 and os.environ.get("DPAMD_WGRAD_G") != "1") else 128

@@ -35,6 +35,11 @@ def _lib():
         lib.dp_bilinear_fwd_ld.argtypes = [V, V, I, I, I, I, I, I, I, V]
         lib.dp_bilinear_bwd_ld.argtypes = [V, V, I, I, I, I, I, I, I, V]
         lib.dp_stem_pack.argtypes = [V, V, L, I, I, I, I, V]
+        lib.dp_affine_augment2.argtypes = [V, V, V, V, V, V, V, V] + [I] * 9 + [V, V, V, V]
+        lib.dp_mask_bbox.argtypes = [V, V, V, V, V, I, I, I, V]
+        lib.dp_compose_crop.argtypes = [V, V, V, V, V, V] + [I] * 7 + [V]
+        lib.dp_extreme_points.argtypes = [V, V, V, I, I, I, I, c_int, V]
+        lib.dp_nellipse_guidance.argtypes = [V, V, V, I, I, I, I, I, F, F, F, F, V]
         _sigs_done = True
     return lib
 
@@ -244,6 +249,116 @@ def affine_augment(img_u8, lab_u8, mats, out_size, mean, std, out_dtype, pad_to:
     B.check(_lib().dp_affine_augment(B.ptr(img_u8), B.ptr(lab_u8), B.ptr(mats), B.ptr(out), B.ptr(out_lab),
                                      bsz, hi, wi, ho, wo, cout, mean_c, std_c, B.stream_ptr()), "affine_augment")
     return out.permute(0, 3, 1, 2), out_lab  # [B,C,H,W] view over NHWC memory (channels-last)
+
+
+def _i32(t, shape, name, device):
+    if t is None:
+        return None
+    t = t.to(device=device, dtype=torch.int32).contiguous()
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected int32 {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def affine_augment2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, interp, lab_fill, clamp, mean, std,
+                    border, channels, out_dtype):
+    import ctypes
+    if out_dtype != torch.bfloat16:
+        raise TypeError("HIP augmentation writes bf16")
+    if not img_u8.is_contiguous():
+        raise ValueError("affine_augment2: the sample store must be contiguous [N,H,W,3] uint8")
+    nslots, hi, wi, _ = img_u8.shape
+    dev = img_u8.device
+    bsz = mats.shape[0]
+    ho, wo = out_size
+    mats = mats.to(device=dev, dtype=torch.float32).contiguous()
+    src_idx = _i32(src_idx, (bsz,), "src_idx", dev)
+    sizes = _i32(sizes, (bsz, 2), "sizes", dev)
+    if clip is not None:
+        clip = clip.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(clip.shape) != (bsz, 8):
+            raise ValueError("clip must be [B,8]")
+    if lab_u8 is not None and (lab_u8.dtype != torch.uint8 or tuple(lab_u8.shape) != (nslots, hi, wi)
+                               or not lab_u8.is_contiguous() or lab_u8.device != dev):
+        raise ValueError("label store must be contiguous uint8 [N,H,W] on the image store's device")
+    # host-side range checks of what the kernel will index with (a bad slot / size is an out-of-bounds read)
+    if src_idx is not None:
+        lo, hi_ = int(src_idx.min()), int(src_idx.max())
+        if lo < 0 or hi_ >= nslots:
+            raise IndexError(f"src_idx outside the store: [{lo}, {hi_}] vs {nslots} slots")
+    elif bsz != nslots:
+        raise ValueError("without src_idx the store must hold exactly the batch")
+    if sizes is not None:
+        if int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi:
+            raise ValueError("sizes outside the slot dimensions")
+    cout = max(3, int(channels))
+    out = torch.empty((bsz, ho, wo, cout), dtype=torch.bfloat16, device=dev)
+    out_lab = torch.empty((bsz, ho, wo), dtype=torch.uint8, device=dev) if lab_u8 is not None else None
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(x) for x in v])    # noqa: E731
+    B.check(_lib().dp_affine_augment2(B.ptr(img_u8), B.ptr(lab_u8), B.ptr(src_idx), B.ptr(sizes), B.ptr(mats),
+                                      B.ptr(clip), B.ptr(out), B.ptr(out_lab), bsz, hi, wi, ho, wo, cout, int(interp),
+                                      int(lab_fill), int(bool(clamp)), f3(mean), f3(std), f3(border), B.stream_ptr()),
+            "affine_augment2")
+    return out.permute(0, 3, 1, 2), out_lab
+
+
+def mask_bbox(mask_u8, src_idx, sizes, mats):
+    if mask_u8.dtype != torch.uint8 or mask_u8.dim() != 3 or not mask_u8.is_contiguous():
+        raise ValueError("mask_bbox: contiguous uint8 [N,H,W]")
+    nslots, hi, wi = mask_u8.shape
+    dev = mask_u8.device
+    bsz = mats.shape[0]
+    mats = mats.to(device=dev, dtype=torch.float32).contiguous()
+    src_idx = _i32(src_idx, (bsz,), "src_idx", dev)
+    sizes = _i32(sizes, (bsz, 2), "sizes", dev)
+    if src_idx is not None:
+        if int(src_idx.min()) < 0 or int(src_idx.max()) >= nslots:
+            raise IndexError("src_idx outside the store")
+    elif bsz != nslots:
+        raise ValueError("without src_idx the store must hold exactly the batch")
+    if sizes is not None and (int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi):
+        raise ValueError("sizes outside the slot dimensions")
+    bbox = torch.empty((bsz, 4), dtype=torch.int32, device=dev)
+    B.check(_lib().dp_mask_bbox(B.ptr(mask_u8), B.ptr(src_idx), B.ptr(sizes), B.ptr(mats), B.ptr(bbox), bsz, hi, wi,
+                                B.stream_ptr()), "mask_bbox")
+    return bbox
+
+
+def compose_crop(mats, bbox, sizes, slot_size, out_size, relax, zero_pad):
+    dev = mats.device
+    bsz = mats.shape[0]
+    mats = mats.to(dtype=torch.float32).contiguous()
+    bbox = _i32(bbox, (bsz, 4), "bbox", dev)
+    sizes = _i32(sizes, (bsz, 2), "sizes", dev)
+    om = torch.empty((bsz, 6), dtype=torch.float32, device=dev)
+    oc = torch.empty((bsz, 8), dtype=torch.float32, device=dev)
+    ob = torch.empty((bsz, 4), dtype=torch.int32, device=dev)
+    B.check(_lib().dp_compose_crop(B.ptr(mats), B.ptr(bbox), B.ptr(sizes), B.ptr(om), B.ptr(oc), B.ptr(ob), bsz,
+                                   int(slot_size[0]), int(slot_size[1]), int(out_size[0]), int(out_size[1]),
+                                   int(relax), int(bool(zero_pad)), B.stream_ptr()), "compose_crop")
+    return om, oc, ob
+
+
+def extreme_points(mask_u8, bbox, random, seed):
+    if mask_u8.dtype != torch.uint8 or mask_u8.dim() != 3 or not mask_u8.is_contiguous():
+        raise ValueError("extreme_points: contiguous uint8 [B,H,W]")
+    bsz, h, w = mask_u8.shape
+    bbox = _i32(bbox, (bsz, 4), "bbox", mask_u8.device)
+    pts = torch.empty((bsz, 4, 2), dtype=torch.int32, device=mask_u8.device)
+    B.check(_lib().dp_extreme_points(B.ptr(mask_u8), B.ptr(bbox), B.ptr(pts), bsz, h, w, int(bool(random)),
+                                     int(seed) & 0x7FFFFFFF, B.stream_ptr()), "extreme_points")
+    return pts
+
+
+def nellipse_guidance(out, pts, channel, alpha, sigma, mean, std):
+    if out.dtype != torch.bfloat16 or out.dim() != 4 or not out.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("nellipse_guidance: channels-last bf16 [B,C,H,W]")
+    bsz, c, h, w = out.shape
+    pts = _i32(pts, (bsz, 4, 2), "pts", out.device)
+    red = torch.empty((bsz, 2), dtype=torch.int32, device=out.device)
+    B.check(_lib().dp_nellipse_guidance(B.ptr(pts), B.ptr(red), B.ptr(out), bsz, h, w, c, int(channel), float(alpha),
+                                        float(sigma), float(mean), float(std), B.stream_ptr()), "nellipse_guidance")
+    return out
 
 
 # ------------------------------------------------------------------ confusion matrix

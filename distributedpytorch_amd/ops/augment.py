@@ -24,7 +24,7 @@ IMAGENET_MEAN = (0.485 * 255, 0.456 * 255, 0.406 * 255)
 IMAGENET_STD = (0.229 * 255, 0.224 * 255, 0.225 * 255)
 
 
-def make_affine_params(batch: int, in_size: Tuple[int, int], out_size: Tuple[int, int],
+def make_affine_params(batch: int, in_size, out_size: Tuple[int, int],
                        scales: Tuple[float, float] = (0.5, 2.0), rots: Tuple[float, float] = (0.0, 0.0),
                        flip_p: float = 0.5, rng: Optional[np.random.Generator] = None,
                        random_crop: bool = True) -> np.ndarray:
@@ -35,10 +35,14 @@ def make_affine_params(batch: int, in_size: Tuple[int, int], out_size: Tuple[int
     crop window of the output size inside the scaled image (centred when the scaled image is
     smaller: the rest is padding), and a horizontal flip."""
     rng = rng or np.random.default_rng()
-    H, W = in_size
+    per_sample = np.ndim(in_size) == 2          # [B, 2] array of (h, w): samples of different sizes (padded cache)
+    if not per_sample:
+        H, W = in_size
     Ho, Wo = out_size
     mats = np.zeros((batch, 6), dtype=np.float32)
     for i in range(batch):
+        if per_sample:
+            H, W = int(in_size[i][0]), int(in_size[i][1])
         s = rng.uniform(scales[0], scales[1])
         th = math.radians(rng.uniform(rots[0], rots[1]))
         flip = rng.random() < flip_p
@@ -105,3 +109,243 @@ def affine_augment(img_u8: torch.Tensor, lab_u8: Optional[torch.Tensor], mats, o
         return _hip_misc.affine_augment(img_u8, lab_u8, mats, out_size, mean, std, out_dtype)
     out, lab = _reference_affine(img_u8, lab_u8, mats.float(), out_size, mean, std)
     return out.to(out_dtype).contiguous(memory_format=torch.channels_last), lab
+
+
+# --------------------------------------------------------------------------------------------------
+# second-generation gather: device-resident dataset cache, bicubic, canvas clip (csrc/augment.hip)
+# --------------------------------------------------------------------------------------------------
+def _reference_affine2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, interp, lab_fill, clamp, mean, std,
+                       border, cout):
+    """Plain-torch implementation of ``dp_affine_augment2`` (CPU path + the numerics reference of the kernel)."""
+    dev = img_u8.device
+    Bn = mats.shape[0]
+    Ho, Wo = out_size
+    ys, xs = torch.meshgrid(torch.arange(Ho, device=dev, dtype=torch.float32),
+                            torch.arange(Wo, device=dev, dtype=torch.float32), indexing="ij")
+    out = torch.zeros(Bn, cout, Ho, Wo, dtype=torch.float32, device=dev)
+    out_lab = torch.empty(Bn, Ho, Wo, dtype=torch.uint8, device=dev) if lab_u8 is not None else None
+    mean_t = torch.tensor(mean, device=dev, dtype=torch.float32).view(3, 1, 1)
+    std_t = torch.tensor(std, device=dev, dtype=torch.float32).view(3, 1, 1)
+    bord = torch.tensor(border, device=dev, dtype=torch.float32).view(3, 1, 1)
+    for b in range(Bn):
+        slot = int(src_idx[b]) if src_idx is not None else b
+        H, W = (int(sizes[b][0]), int(sizes[b][1])) if sizes is not None else tuple(img_u8.shape[1:3])
+        m = mats[b].to(dev)
+        xi = m[0] * xs + m[1] * ys + m[2]
+        yi = m[3] * xs + m[4] * ys + m[5]
+        inside = torch.ones_like(xi, dtype=torch.bool)
+        if clip is not None:
+            q = clip[b].to(dev)
+            cx, cy = q[0] * xs + q[1] * ys + q[2], q[3] * xs + q[4] * ys + q[5]
+            inside = (cx > -0.5) & (cy > -0.5) & (cx < q[6] - 0.5) & (cy < q[7] - 0.5)
+        src = img_u8[slot, :H, :W].permute(2, 0, 1).float() - bord           # border == 0 in this space
+        grid = torch.stack([2 * xi / max(W - 1, 1) - 1, 2 * yi / max(H - 1, 1) - 1], dim=-1)[None]
+        smp = F.grid_sample(src[None], grid, mode="bicubic" if interp == 2 else "bilinear", padding_mode="zeros",
+                            align_corners=True)[0] + bord
+        smp = torch.where(inside[None], smp, bord.expand_as(smp))
+        if clamp:
+            smp = smp.clamp(0.0, 255.0)
+        out[b, :3] = (smp - mean_t) / std_t
+        if lab_u8 is not None:
+            xr, yr = torch.floor(xi + 0.5).long(), torch.floor(yi + 0.5).long()
+            ok = inside & (xr >= 0) & (xr < W) & (yr >= 0) & (yr < H)
+            v = lab_u8[slot][yr.clamp(0, H - 1), xr.clamp(0, W - 1)]
+            out_lab[b] = torch.where(ok, v, torch.full_like(v, lab_fill))
+    return out, out_lab
+
+
+@torch.no_grad()
+def affine_augment2(img_u8: torch.Tensor, lab_u8: Optional[torch.Tensor], mats: torch.Tensor,
+                    out_size: Tuple[int, int], src_idx: Optional[torch.Tensor] = None,
+                    sizes: Optional[torch.Tensor] = None, clip: Optional[torch.Tensor] = None,
+                    interp: str = "bilinear", lab_fill: int = 255, clamp: bool = False,
+                    mean: Sequence[float] = IMAGENET_MEAN, std: Sequence[float] = IMAGENET_STD,
+                    border: Optional[Sequence[float]] = None, channels: int = 3,
+                    out_dtype: torch.dtype = torch.bfloat16):
+    """General inverse-affine gather over a (possibly padded, device-resident) uint8 sample store.
+
+    ``img_u8`` [N,H,W,3], ``lab_u8`` [N,H,W] or None; ``mats`` [B,6] out→source maps; ``src_idx`` int32 [B] slot of
+    each batch element (default ``arange``); ``sizes`` int32 [B,2] valid (h, w) of each element's slot; ``clip``
+    [B,8] out→canvas map + canvas extent (pixels outside the canvas take ``border`` / ``lab_fill``);
+    ``interp`` 'bilinear' | 'bicubic' (Keys a=−0.75 as ``cv2.INTER_CUBIC``); ``border``: out-of-source image value
+    in 0..255 space (default: the mean colour, i.e. 0 after normalisation).  Returns
+    ``(image [B,channels,Ho,Wo] channels-last, label uint8 [B,Ho,Wo] | None)``; channels ≥ 3 beyond RGB are zero
+    (the guidance channel is written by ``nellipse_guidance_``)."""
+    if border is None:
+        border = mean
+    ip = {"bilinear": 1, "bicubic": 2}[interp]
+    Bn = mats.shape[0]
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3
+    assert mats.shape == (Bn, 6) and (src_idx is not None or img_u8.shape[0] == Bn)
+    if B.use_hip(img_u8):
+        from . import _hip_misc
+        return _hip_misc.affine_augment2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, ip, lab_fill,
+                                         clamp, mean, std, border, channels, out_dtype)
+    out, lab = _reference_affine2(img_u8, lab_u8, src_idx, sizes, mats.float(), clip, out_size, ip, lab_fill, clamp,
+                                  mean, std, border, channels)
+    return out.to(out_dtype).contiguous(memory_format=torch.channels_last), lab
+
+
+def make_warp_params(batch: int, sizes, rots: Tuple[float, float] = (-20.0, 20.0),
+                     scales: Tuple[float, float] = (0.75, 1.25), flip_p: float = 0.5,
+                     rng: Optional[np.random.Generator] = None) -> np.ndarray:
+    """Canvas→source maps [B,6] of the reference's ``RandomHorizontalFlip`` + ``ScaleNRotate`` chain
+    (`/root/reference/custom_transforms.py:202-218`, `:91-126`): a flip of the source, then a rotation by ``rot``
+    and scale ``sc`` about the image centre onto a canvas of the SAME size.  ``rot``/``sc`` follow the reference's
+    centred-range quirk: ``(hi−lo)·U − (hi−lo)/2`` (+1 for the scale), whatever ``lo``/``hi`` are."""
+    rng = rng or np.random.default_rng()
+    mats = np.zeros((batch, 6), dtype=np.float32)
+    for i in range(batch):
+        h, w = int(sizes[i][0]), int(sizes[i][1])
+        flip = rng.random() < flip_p
+        rot = (rots[1] - rots[0]) * rng.random() - (rots[1] - rots[0]) / 2
+        sc = (scales[1] - scales[0]) * rng.random() - (scales[1] - scales[0]) / 2 + 1
+        # forward (source→canvas) matrix of cv2.getRotationMatrix2D((w/2, h/2), rot, sc); invert it
+        a = sc * math.cos(math.radians(rot))
+        bb = sc * math.sin(math.radians(rot))
+        cx, cy = w / 2.0, h / 2.0
+        fwd = np.array([[a, bb, (1 - a) * cx - bb * cy], [-bb, a, bb * cx + (1 - a) * cy], [0, 0, 1]], dtype=np.float64)
+        inv = np.linalg.inv(fwd)
+        if flip:    # the flip acts on the source first: x_src = (w − 1) − x
+            inv = np.array([[-1, 0, w - 1], [0, 1, 0], [0, 0, 1]], dtype=np.float64) @ inv
+        mats[i] = inv[:2].reshape(-1)
+    return mats
+
+
+@torch.no_grad()
+def mask_bbox(mask_u8: torch.Tensor, mats: torch.Tensor, src_idx=None, sizes=None) -> torch.Tensor:
+    """int32 [B,4] inclusive (x_min, y_min, x_max, y_max) of the nearest-warped mask on its canvas; (·,·,−1,−1) when
+    empty — ``helpers.get_bbox`` of ``ScaleNRotate``'s output (`/root/reference/custom_transforms.py:359`)."""
+    if B.use_hip(mask_u8):
+        from . import _hip_misc
+        return _hip_misc.mask_bbox(mask_u8, src_idx, sizes, mats)
+    Bn = mats.shape[0]
+    out = torch.empty(Bn, 4, dtype=torch.int32)
+    for b in range(Bn):
+        slot = int(src_idx[b]) if src_idx is not None else b
+        H, W = (int(sizes[b][0]), int(sizes[b][1])) if sizes is not None else tuple(mask_u8.shape[1:3])
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
+                                indexing="ij")
+        m = mats[b].float()
+        xr = torch.floor(m[0] * xs + m[1] * ys + m[2] + 0.5).long()
+        yr = torch.floor(m[3] * xs + m[4] * ys + m[5] + 0.5).long()
+        ok = (xr >= 0) & (xr < W) & (yr >= 0) & (yr < H)
+        on = ok & (mask_u8[slot][yr.clamp(0, H - 1), xr.clamp(0, W - 1)] != 0)
+        if on.any():
+            yy, xx = torch.where(on)
+            out[b] = torch.tensor([xx.min(), yy.min(), xx.max(), yy.max()], dtype=torch.int32)
+        else:
+            out[b] = torch.tensor([2 ** 31 - 1, 2 ** 31 - 1, -1, -1], dtype=torch.int32)
+    return out
+
+
+@torch.no_grad()
+def compose_crop(mats: torch.Tensor, bbox: torch.Tensor, out_size: Tuple[int, int], relax: int = 50,
+                 zero_pad: bool = True, sizes=None, slot_size: Tuple[int, int] = (0, 0)):
+    """Maps of ``CropFromMaskStatic(relax, zero_pad)`` + ``FixedResize(out_size)`` composed with the warp
+    (`/root/reference/custom_transforms.py:343-371`, `:156-196`).  Returns ``(mats [B,6] out→source,
+    clip [B,8] out→canvas + extent, crop_bbox int32 [B,4])``."""
+    Ho, Wo = out_size
+    if B.use_hip(mats):
+        from . import _hip_misc
+        return _hip_misc.compose_crop(mats, bbox, sizes, slot_size, out_size, relax, zero_pad)
+    Bn = mats.shape[0]
+    om, oc, ob = torch.zeros(Bn, 6), torch.zeros(Bn, 8), torch.zeros(Bn, 4, dtype=torch.int32)
+    for b in range(Bn):
+        H, W = (int(sizes[b][0]), int(sizes[b][1])) if sizes is not None else slot_size
+        x0, y0, x1, y1 = [int(v) for v in bbox[b]]
+        if x1 < 0:
+            om[b] = torch.tensor([0, 0, -1e6, 0, 0, -1e6])
+            oc[b] = torch.tensor([0, 0, -1e6, 0, 0, -1e6, W, H])
+            ob[b] = torch.tensor([0, 0, -1, -1], dtype=torch.int32)
+            continue
+        x0, y0, x1, y1 = x0 - relax, y0 - relax, x1 + relax, y1 + relax
+        if not zero_pad:
+            x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, W - 1), min(y1, H - 1)
+        ob[b] = torch.tensor([x0, y0, x1, y1], dtype=torch.int32)
+        sx, sy = (x1 - x0 + 1) / Wo, (y1 - y0 + 1) / Ho
+        ca, cc, ce, cf = sx, 0.5 * sx - 0.5 + x0, sy, 0.5 * sy - 0.5 + y0
+        oc[b] = torch.tensor([ca, 0, cc, 0, ce, cf, W, H])
+        m = mats[b].float()
+        om[b] = torch.stack([m[0] * ca, m[1] * ce, m[0] * cc + m[1] * cf + m[2],
+                             m[3] * ca, m[4] * ce, m[3] * cc + m[4] * cf + m[5]])
+    return om, oc, ob
+
+
+@torch.no_grad()
+def extreme_points(mask_u8: torch.Tensor, random: bool = True, seed: int = 0) -> torch.Tensor:
+    """int32 [B,4,2] (x, y) of the left / right / top / bottom extreme pixel of each mask [B,H,W]; among the mask
+    pixels on the extreme line one is drawn at random (training) or the median one taken (validation) —
+    ``helpers.extreme_points`` / ``extreme_points_fixed`` with ``pert=0`` (`/root/reference/custom_transforms.py:40-42`).
+    Empty masks give −1."""
+    ident = torch.tensor([1.0, 0, 0, 0, 1, 0]).repeat(mask_u8.shape[0], 1)
+    if B.use_hip(mask_u8):
+        from . import _hip_misc
+        bbox = _hip_misc.mask_bbox(mask_u8, None, None, ident.to(mask_u8.device))
+        return _hip_misc.extreme_points(mask_u8, bbox, random, seed)
+    Bn, H, W = mask_u8.shape
+    pts = torch.full((Bn, 4, 2), -1, dtype=torch.int32)
+    g = torch.Generator().manual_seed(seed)
+    for b in range(Bn):
+        yy, xx = torch.where(mask_u8[b] != 0)
+        if yy.numel() == 0:
+            continue
+        for side, (fixed_is_x, val) in enumerate(((True, xx.min()), (True, xx.max()), (False, yy.min()), (False, yy.max()))):
+            cand = torch.where(xx == val)[0] if fixed_is_x else torch.where(yy == val)[0]
+            other = (yy if fixed_is_x else xx)[cand]
+            other, _ = torch.sort(other)
+            k = int(torch.randint(0, len(other), (1,), generator=g)) if random else len(other) // 2
+            pts[b, side] = torch.tensor([int(val), int(other[k])] if fixed_is_x else [int(other[k]), int(val)],
+                                        dtype=torch.int32)
+    return pts
+
+
+@torch.no_grad()
+def nellipse_guidance_(out: torch.Tensor, pts: torch.Tensor, channel: int = 3, alpha: float = 0.6,
+                       sigma: float = 10.0, mean: float = 0.0, std: float = 1.0) -> torch.Tensor:
+    """Writes the ``NEllipseWithGaussians`` guidance map (0..255, then ``(v−mean)/std``) of the four points
+    ``pts`` [B,4,2] into channel ``channel`` of the channels-last tensor ``out`` [B,C,H,W]
+    (`/root/reference/custom_transforms.py:30-51`; maths of data/nellipse.py)."""
+    if B.use_hip(out):
+        from . import _hip_misc
+        return _hip_misc.nellipse_guidance(out, pts, channel, alpha, sigma, mean, std)
+    Bn, C, H, W = out.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    for b in range(Bn):
+        f = pts[b].float()
+        if (f < 0).any():
+            out[b, channel] = (0.0 - mean) / std
+            continue
+        d = sum(torch.sqrt((xs - f[k, 0]) ** 2 + (ys - f[k, 1]) ** 2) for k in range(4))
+        dref = max(float(sum(torch.sqrt(((f - f[k]) ** 2).sum(1)))) for k in range(4))
+        dmin = float(d.min())
+        z1 = (d <= dref).float() if dref - dmin < 1e-6 else (1 - (d - dmin) / (dref - dmin)).clamp(0, 1)
+        z2 = torch.zeros_like(z1)
+        for k in range(4):
+            z2 = torch.maximum(z2, torch.exp(-4 * math.log(2) * ((xs - f[k, 0]) ** 2 + (ys - f[k, 1]) ** 2) / sigma ** 2))
+        z = 255 * z1 + alpha * 255 * z2
+        z = (z * (255.0 / max(float(z.max()), 1e-10))).clamp(max=255.0)
+        out[b, channel] = ((z - mean) / std).to(out.dtype)
+    return out
+
+
+@torch.no_grad()
+def instance_augment(img_u8: torch.Tensor, gt_u8: torch.Tensor, src_idx: torch.Tensor, sizes: torch.Tensor,
+                     warp_mats: torch.Tensor, out_size: Tuple[int, int] = (512, 512), relax: int = 50,
+                     zero_pad: bool = True, alpha: float = 0.6, random_points: bool = True, seed: int = 0,
+                     out_dtype: torch.dtype = torch.bfloat16):
+    """The reference's whole training transform chain for the instance task
+    (`/root/reference/train_pascal.py:123-134`) on the device: Flip → ScaleNRotate (``warp_mats``) →
+    CropFromMaskStatic(relax, zero_pad) → FixedResize(out_size) → NEllipseWithGaussians(alpha) →
+    ConcatInputs → ToTensor.  Returns ``(concat [B,4,Ho,Wo] channels-last, values 0..255 as the reference feeds
+    them; crop_gt [B,1,Ho,Wo] float {0,1}; crop_bbox int32 [B,4])``.  ONE bicubic resampling replaces the
+    reference's two (warp, then resize): fewer interpolation passes, same geometry."""
+    warp_mats = warp_mats.to(img_u8.device)
+    bbox = mask_bbox(gt_u8, warp_mats, src_idx, sizes)
+    mats, clip, crop_bbox = compose_crop(warp_mats, bbox, out_size, relax, zero_pad, sizes, tuple(img_u8.shape[1:3]))
+    x, crop_gt = affine_augment2(img_u8, gt_u8, mats, out_size, src_idx, sizes, clip, interp="bicubic", lab_fill=0,
+                                 clamp=True, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), border=(0.0, 0.0, 0.0),
+                                 channels=4, out_dtype=out_dtype)
+    pts = extreme_points(crop_gt, random_points, seed)
+    nellipse_guidance_(x, pts, 3, alpha)
+    return x, crop_gt.unsqueeze(1).to(torch.float32), crop_bbox

@@ -78,7 +78,7 @@ def _small_all_reduce(packed: torch.Tensor, pg) -> None:
     (parallel.p2p, DPAMD_SYNCBN_P2P=1, default group, GPU) or the backend's all-reduce."""
     if packed.is_cuda and pg is None:
         from ..parallel import p2p
-        if p2p.ENABLED and packed.numel() <= p2p._MAXN and packed.is_contiguous():
+        if p2p.resolve() and packed.numel() <= p2p._MAXN and packed.is_contiguous():
             p2p.default_instance().all_reduce_(packed)
             return
     if packed.is_cuda:
@@ -115,7 +115,7 @@ class _BatchNormActTrain(torch.autograd.Function):
             elif conv_stats is not None:
                 from ..parallel import p2p
                 pg_ = None if group is True else group
-                if pg_ is None and p2p.ENABLED and conv_stats.numel() > p2p._MAXN:
+                if pg_ is None and p2p.resolve() and conv_stats.numel() > p2p._MAXN:
                     red = conv_stats.sum(0)                   # too long for the one-shot kernel's slots
                     s, ss = red[0], red[1]
                 else:

@@ -95,3 +95,12 @@ def join(device: Optional[torch.device] = None) -> None:
         for st in _streams[idx]:
             cur.wait_stream(st)
         _dirty[idx] = False
+
+
+def join_into(stream: "torch.cuda.Stream", device: Optional[torch.device] = None) -> None:
+    """Make ``stream`` (not the current one) wait for all work enqueued on the aux stream(s) so far.  The
+    step's own stream stays un-joined (``join`` still has to be called before IT consumes aux results)."""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    if _dirty.get(idx):
+        for st in _streams[idx]:
+            stream.wait_stream(st)

@@ -54,8 +54,11 @@ def _view_like(flat: torch.Tensor, offset: int, p: torch.Tensor) -> torch.Tensor
 
 class ParamArena:
     def __init__(self, named_param_groups: Sequence[Iterable], bucket_bytes: int = 64 << 20,
-                 lowp_dtype: Optional[torch.dtype] = None):
-        """``named_param_groups``: one iterable of ``(name, Parameter)`` per optimiser group."""
+                 lowp_dtype: Optional[torch.dtype] = None, tail_bytes: int = 0, shard_align: int = 1):
+        """``named_param_groups``: one iterable of ``(name, Parameter)`` per optimiser group.
+        ``tail_bytes``: upper bound for the LAST bucket (the one whose all-reduce nothing overlaps; 0 = no
+        special tail).  ``shard_align``: every bucket's element count is a multiple of it (reduce-scatter
+        shards); slots are 64-element aligned, so any world size dividing 64 costs nothing."""
         entries = []
         seen = set()
         for gi, group in enumerate(named_param_groups):
@@ -111,6 +114,23 @@ class ParamArena:
             cur.end = span_end
             s.bucket = cur.index
         self.buckets.append(cur)
+        # ---- small tail: split the last bucket so that its final run is at most tail_bytes ----
+        tail_cap = tail_bytes // 4
+        last = self.buckets[-1]
+        if tail_cap > 0 and last.end - last.start > tail_cap and len(last.slots) > 1:
+            k = len(last.slots) - 1          # the tail always keeps the last slot
+            while k > 1 and last.end - self.slots[last.slots[k - 1]].offset <= tail_cap:
+                k -= 1
+            head_slots, tail_slots = last.slots[:k], last.slots[k:]
+            cut = self.slots[tail_slots[0]].offset
+            self.buckets[-1] = Bucket(last.index, last.start, cut, head_slots)
+            tail = Bucket(len(self.buckets), cut, last.end, tail_slots)
+            self.buckets.append(tail)
+            for si in tail_slots:
+                self.slots[si].bucket = tail.index
+        if shard_align > 1 and any((b.end - b.start) % shard_align for b in self.buckets):
+            if _ALIGN % shard_align:
+                raise ValueError(f"world size {shard_align} does not divide the arena alignment {_ALIGN}")
         # ---- optimiser segments: maximal runs of equal group ----
         self.segments: List[tuple] = []  # (start, end, group)
         st, g = 0, self.slots[0].group

@@ -15,7 +15,18 @@ realises the file's TODO header (`:1-8`).  Here:
 
 xGMI note: the mesh is point-to-point, 7 links per GPU, and ring traffic is
 per-link bound, so buckets default to 64 MiB — few, large messages that RCCL can split across all
-links — rather than DDP's NVSwitch-era 25 MiB.
+links — rather than DDP's NVSwitch-era 25 MiB.  The LAST bucket (the stem and the first stages,
+whose gradients exist only when backward ends) is kept small (``tail_bytes``): its all-reduce is
+the only one nothing can hide.
+
+Launch choreography on the GPU: the gradients of a bucket are written by kernels of two streams —
+weight gradients on the low-priority auxiliary stream (``ops.streams``), BN affine gradients on the
+step's own stream.  A bucket's collective is issued from a dedicated COMM-LAUNCH stream that waits
+on an event recorded on the step's stream and on the auxiliary stream(s) at the moment the
+bucket's last gradient kernel was enqueued; the step's stream itself never waits for the weight
+gradients mid-backward (round 1 joined it at every launch).  ``DPAMD_DDP_MODE=rs_ag`` replaces
+each all-reduce by an in-place reduce-scatter + all-gather pair (the direct full-mesh form of
+SURVEY.md §5.8: every rank owns 1/world of the bucket and talks to its 7 peers at once).
 """
 from __future__ import annotations
 
@@ -38,6 +49,10 @@ _SYNC = os.environ.get("DPAMD_DDP_SYNC", "0") != "0"
 # DPAMD_DDP_FORCE=1: run the whole communication path (broadcast, bucket all-reduces, waits) even in
 # a 1-rank group — rehearses the RCCL stream/event choreography on a single GPU
 _FORCE = os.environ.get("DPAMD_DDP_FORCE", "0") != "0"
+# DPAMD_DDP_MODE: "allreduce" (default) | "rs_ag" (reduce-scatter + all-gather per bucket, RCCL only)
+_MODE = os.environ.get("DPAMD_DDP_MODE", "allreduce")
+# DPAMD_COMM_LAUNCH_STREAM=0: issue collectives from the step's stream after joining the aux stream (round-1 form)
+_COMM_STREAM = os.environ.get("DPAMD_COMM_LAUNCH_STREAM", "1") != "0"
 
 
 def _dbg(msg: str) -> None:
@@ -58,14 +73,22 @@ class DistributedDataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, param_groups: Optional[Sequence[Iterable]] = None,
                  bucket_bytes: int = 64 << 20, lowp_dtype: Optional[torch.dtype] = None,
-                 process_group=None, broadcast_buffers: bool = True):
+                 process_group=None, broadcast_buffers: bool = True, tail_bytes: Optional[int] = None,
+                 mode: Optional[str] = None):
         super().__init__()
         self.module = module
         self.process_group = process_group
         self.world_size = _world(process_group)
         if param_groups is None:
             param_groups = [list(module.named_parameters())]
-        self.arena = ParamArena(param_groups, bucket_bytes, lowp_dtype)
+        if tail_bytes is None:
+            tail_bytes = int(os.environ.get("DPAMD_DDP_TAIL_MB", "8")) << 20
+        self.mode = mode or _MODE
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError("DDP mode must be 'allreduce' or 'rs_ag'")
+        self.arena = ParamArena(param_groups, bucket_bytes, lowp_dtype, tail_bytes=tail_bytes,
+                                shard_align=max(self.world_size, 1) if self.mode == "rs_ag" else 1)
+        self._comm_stream = None
         self._pending: List[int] = []
         self._ready: List[bool] = []
         self._works: list = []
@@ -73,6 +96,8 @@ class DistributedDataParallel(nn.Module):
         self._sync_enabled = True
         self.stats = {"buckets_launched": 0, "bytes_reduced": 0}
         self._comm = self.world_size > 1 or (_FORCE and dist.is_initialized())
+        self._rank = dist.get_rank(process_group) if (dist.is_available() and dist.is_initialized()) else 0
+        self._cs_dirty = False
         if self._comm:
             self._broadcast_initial_state(broadcast_buffers)
         self._install_hooks()
@@ -133,18 +158,52 @@ class DistributedDataParallel(nn.Module):
             self._launch(self._next)
             self._next += 1
 
+    def _launch_stream(self, device):
+        """The comm-launch stream of this replica (created on first use; GPU + RCCL-style backends only)."""
+        if not _COMM_STREAM:
+            return None
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device, priority=-1)
+        return self._comm_stream
+
+    def _collective(self, g: torch.Tensor) -> None:
+        from .dist_env import all_reduce_, _stage_through_host
+        pg = self.process_group
+        if self.mode == "rs_ag" and self.world_size > 1 and not _stage_through_host(g, pg) \
+                and dist.get_backend(pg) == "nccl":
+            # in-place reduce-scatter (this rank's shard of the bucket receives the sum) + in-place all-gather:
+            # bucket sizes are multiples of world (ParamArena shard_align), so the shards tile the bucket exactly
+            n = g.numel() // self.world_size
+            shard = g[self._rank * n:(self._rank + 1) * n]
+            w1 = dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=pg, async_op=not _SYNC)
+            w2 = dist.all_gather_into_tensor(g, shard, group=pg, async_op=not _SYNC)
+            for w in (w1, w2):
+                if w is not None:
+                    self._works.append(w)
+            return
+        work = all_reduce_(g, pg, async_op=not _SYNC)
+        if work is not None:
+            self._works.append(work)
+
     def _launch(self, b: int) -> None:
         if not self._comm:
             return
         g = self.arena.bucket_grad(b)
-        if g.is_cuda:
-            streams.join(g.device)     # weight gradients are produced on the aux stream (ops.streams)
         _dbg(f"launch bucket {b} numel {g.numel()}")
         self._order.append(b)
-        from .dist_env import all_reduce_
-        work = all_reduce_(g, self.process_group, async_op=not _SYNC)
-        if work is not None:
-            self._works.append(work)
+        cs = self._launch_stream(g.device) if g.is_cuda else None
+        if cs is not None:
+            # everything that writes this bucket has been ENQUEUED (its hooks fired): the comm-launch stream waits
+            # for that point of the step's stream (event) and of the weight-gradient stream(s); nobody else waits
+            cs.wait_stream(torch.cuda.current_stream(g.device))
+            streams.join_into(cs, g.device)
+            with torch.cuda.stream(cs):
+                self._collective(g)
+            self._cs_dirty = True
+        else:
+            if g.is_cuda:
+                streams.join(g.device)     # weight gradients are produced on the aux stream (ops.streams)
+            self._collective(g)
         self.stats["buckets_launched"] += 1
         self.stats["bytes_reduced"] += g.numel() * 4
 
@@ -167,6 +226,10 @@ class DistributedDataParallel(nn.Module):
                 _dbg(f"wait work {i}/{len(self._works)}")
                 w.wait()
         if self.arena.flat_g.is_cuda:
+            if getattr(self, "_cs_dirty", False):
+                # blocking collectives (gloo staging, DPAMD_DDP_SYNC) ran ON the comm-launch stream
+                torch.cuda.current_stream(self.arena.flat_g.device).wait_stream(self._comm_stream)
+                self._cs_dirty = False
             streams.join(self.arena.flat_g.device)
         from . import debug
         if debug.ENABLED and self._sync_enabled and self._comm:

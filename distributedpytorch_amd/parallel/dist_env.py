@@ -38,6 +38,20 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 600,
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The host driver of this platform only supports dmabuf IPC: RCCL's peer mappings and hipIpc*MemHandle
+    # need HSA_ENABLE_IPC_MODE_LEGACY=0, and ROCr reads HSA_* ONCE, at hsa_init — i.e. at the first HIP call.
+    # It is therefore set here, BEFORE torch.cuda.is_available()/set_device() below create the context (the
+    # package __init__ sets it too, for callers that touch the GPU before rendezvous), and a multi-rank GPU job
+    # whose runtime is already up with another value fails loudly instead of dying later in
+    # `hipIpcGetMemHandle: invalid argument`.
+    if device != "cpu":
+        already_up = torch.cuda.is_initialized()
+        if not already_up:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            raise RuntimeError("multi-rank GPU job: export HSA_ENABLE_IPC_MODE_LEGACY=0 before the first GPU call "
+                               "(this process already initialised the GPU runtime without it)"
+                               if already_up else "multi-rank GPU job needs HSA_ENABLE_IPC_MODE_LEGACY=0")
     use_gpu = torch.cuda.is_available() and device != "cpu"
     if use_gpu:
         ngpu = torch.cuda.device_count()
@@ -53,12 +67,20 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 600,
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # xGMI / dmabuf IPC requirement of this platform (see task environment notes)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kwargs = dict(backend=backend, rank=rank, world_size=world,
                       timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
             kwargs["device_id"] = dev
+            # RCCL's kernels go to a HIGH-priority stream: a bucket all-reduce launched mid-backward must not
+            # queue behind every ready compute workgroup of the step (SURVEY.md §5.8 "dedicated high-priority
+            # comm stream"); it takes a handful of CUs for ~1 ms per 64 MiB bucket over the 7 xGMI links.
+            if os.environ.get("DPAMD_COMM_PRIORITY", "high") == "high":
+                try:
+                    opts = dist.ProcessGroupNCCL.Options()
+                    opts.is_high_priority_stream = True
+                    kwargs["pg_options"] = opts
+                except Exception:      # pragma: no cover - older bindings
+                    pass
         dist.init_process_group(**kwargs)
     return DistInfo(rank, local_rank, world, backend if (world > 1 or force) else "none", dev)
 

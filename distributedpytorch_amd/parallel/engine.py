@@ -69,9 +69,21 @@ class TrainEngine:
         # DPAMD_MAIN_PRIORITY=high additionally runs the step itself on a HIGH-priority stream (961-962 on one
         # GPU).  Not the default: RCCL's kernels run at normal priority and would be dispatched behind every
         # compute kernel, and two ranks SHARING one GPU (the rehearsal of tests/test_gpu_p2p.py) stalled with it.
+        # Why it stalls shared-GPU ranks (round-1 ADVICE): the one-shot SyncBN kernel (csrc/p2p_allreduce.hip) SPINS
+        # until every peer's granules arrive.  On a high-priority queue the spinning kernel of rank A outranks the
+        # (normal-priority, or equally high but later) kernel of rank B that would produce those granules when both
+        # share a device, so nothing progresses until the bounded spin times out — and a timed-out reduction returns
+        # partial sums.  High priority is therefore refused whenever peers exist (world > 1): the step's kernels and
+        # the collectives they wait on must be dispatched at the same level.
         self._main = None
         if self.on_gpu and os.environ.get("DPAMD_MAIN_PRIORITY", "normal") == "high":
-            self._main = torch.cuda.Stream(device=self.device, priority=-1)
+            if dist_env.get_world_size() > 1:
+                if dist_env.is_master():
+                    import sys
+                    print("[dpamd] DPAMD_MAIN_PRIORITY=high ignored: with world_size > 1 the step's stream must not "
+                          "outrank the collectives it waits for", file=sys.stderr)
+            else:
+                self._main = torch.cuda.Stream(device=self.device, priority=-1)
 
     # ------------------------------------------------------------------
     def prepare_input(self, images: torch.Tensor) -> torch.Tensor:
@@ -143,8 +155,11 @@ class TrainEngine:
                 all_sync = bool(bns) and all(m.sync for m in bns)
                 debug.check_replicas_equal(self.ddp.arena.flat_p, self.model.buffers() if all_sync else ())
             from . import p2p
-            if p2p._default is not None and self.global_step % p2p.CHECK_EVERY == 0:
-                p2p._default.check()      # a peer that never arrived (bounded spin) surfaces here
+            if p2p._default is not None:
+                if self.global_step == 1:
+                    p2p.check_first_step()    # a timed-out (partial) reduction must never feed a second step
+                elif self.global_step % p2p.CHECK_EVERY == 0:
+                    p2p._default.check()      # a peer that never arrived (bounded spin) surfaces here
         return loss.detach()
 
     @torch.no_grad()

@@ -14,7 +14,12 @@ from torch.utils.data import Sampler
 
 class DistributedSampler(Sampler[int]):
     def __init__(self, dataset_len: int, num_replicas: Optional[int] = None, rank: Optional[int] = None,
-                 shuffle: bool = True, seed: int = 0, drop_last: bool = True):
+                 shuffle: bool = True, seed: int = 0, drop_last: bool = True, pad: bool = True):
+        """``pad=False`` (with ``drop_last=False``): no wrap-around padding — every sample is visited exactly once
+        over all ranks and shard lengths differ by at most one.  For EVALUATION only (metrics are merged at the
+        end, so ranks need not take the same number of steps): duplicated samples would be counted twice in the
+        merged confusion matrix / Jaccard sums; the reference evaluates each validation object exactly once
+        (`/root/reference/train_pascal.py:237`, `:298`)."""
         if hasattr(dataset_len, "__len__"):
             dataset_len = len(dataset_len)
         if num_replicas is None:
@@ -26,10 +31,13 @@ class DistributedSampler(Sampler[int]):
         self.n, self.replicas, self.rank = int(dataset_len), num_replicas, rank
         self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.epoch = 0
+        self.pad = pad or drop_last
         if drop_last:
             self.per_rank = self.n // num_replicas
-        else:
+        elif self.pad:
             self.per_rank = math.ceil(self.n / num_replicas)
+        else:
+            self.per_rank = len(range(rank, self.n, num_replicas))
         self.total = self.per_rank * num_replicas
 
     def set_epoch(self, epoch: int) -> None:
@@ -45,6 +53,8 @@ class DistributedSampler(Sampler[int]):
             order = torch.randperm(self.n, generator=g).tolist()
         else:
             order = list(range(self.n))
+        if not self.pad:
+            return iter(order[self.rank::self.replicas])
         if self.total <= len(order):
             order = order[:self.total]
         else:  # pad by wrapping so every rank gets the same count

@@ -56,8 +56,7 @@ def save_checkpoint(path: str, model: nn.Module, optimizer=None, extra: Optional
     if dist_env.is_master():
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         _atomic_save(reference_state_dict(model), path)
-        side: Dict[str, Any] = {"extra": dict(extra or {}),
-                                "rng_cpu": torch.get_rng_state()}
+        side: Dict[str, Any] = {"extra": dict(extra or {}), **capture_rng_state()}
         if optimizer is not None:
             side["optimizer"] = optimizer.state_dict()
         _atomic_save(side, path + ".state")
@@ -88,9 +87,40 @@ def load_checkpoint(path: str, model: nn.Module, optimizer=None, strict: bool = 
         extra = side.get("extra", {})
         if optimizer is not None and "optimizer" in side:
             optimizer.load_state_dict(side["optimizer"])
-        if "rng_cpu" in side:
-            torch.set_rng_state(side["rng_cpu"])
+        restore_rng_state(side)
     return extra
+
+
+def capture_rng_state() -> Dict[str, Any]:
+    """Everything that decides the random stream of a resumed run: torch CPU and GPU generators, NumPy's global
+    generator (the CPU transforms draw from it) and the fused-dropout call counter (``ops.batchnorm`` derives
+    each dropout mask's seed from torch's seed, the rank and that counter — no device RNG state is involved).
+    Only tensors / ints / strings, so the sidecar stays loadable with ``weights_only=True``."""
+    import numpy as np
+    from ..ops import batchnorm as _bn
+    st: Dict[str, Any] = {"rng_cpu": torch.get_rng_state(), "torch_seed": int(torch.initial_seed()),
+                          "dropout_calls": int(_bn._drop_calls)}
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        st["rng_cuda"] = torch.cuda.get_rng_state()
+    name, keys, pos, has_gauss, cached = np.random.get_state()
+    st["np_rng"] = {"name": str(name), "keys": torch.from_numpy(keys.astype(np.int64)), "pos": int(pos),
+                    "has_gauss": int(has_gauss), "cached": float(cached)}
+    return st
+
+
+def restore_rng_state(side: Dict[str, Any]) -> None:
+    import numpy as np
+    from ..ops import batchnorm as _bn
+    if "rng_cpu" in side:
+        torch.set_rng_state(side["rng_cpu"])
+    if "rng_cuda" in side and torch.cuda.is_available():
+        torch.cuda.set_rng_state(side["rng_cuda"])
+    if "dropout_calls" in side:
+        _bn._drop_calls = int(side["dropout_calls"])
+    npst = side.get("np_rng")
+    if npst:
+        np.random.set_state((npst["name"], npst["keys"].numpy().astype(np.uint32), int(npst["pos"]),
+                             int(npst["has_gauss"]), float(npst["cached"])))
 
 
 def run_dir(save_dir_root: str, resume_epoch: int = 0) -> str:

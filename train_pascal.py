@@ -5,8 +5,11 @@ functions, distributed sampler, save on master only, non-blocking label copies, 
 device from the local rank, explicit rendezvous).
 
     # 1 GPU, synthetic VOC-shaped data, the BASELINE.json headline config
-    python train_pascal.py --synthetic --model deeplabv3plus_resnet101 --crop 513 --trainBatch 32
-    # 8 GPUs on one node (RCCL over xGMI)
+    python train_pascal.py --synthetic --model deeplabv3plus_resnet101 --crop 513 --trainBatch 128
+    # 8 GPUs on one node (RCCL over xGMI): ONE command, as the reference (`train_pascal.py:92`) — the parent
+    # starts the 8 rank processes itself before touching the GPU (parallel.launch) ...
+    python train_pascal.py --gpus 8 --synthetic --model deeplabv3plus_resnet101 --sync-bn
+    # ... or under torchrun (HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported: dmabuf IPC for RCCL / HIP IPC)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         train_pascal.py --synthetic --model deeplabv3plus_resnet101 --sync-bn
     # CPU / gloo plumbing configuration
@@ -51,6 +54,7 @@ from distributedpytorch_amd.parallel import (DistributedSampler, TrainEngine, di
 from distributedpytorch_amd.utils import (JsonlLogger, LR_Scheduler, SegmentationMultiLosses,  # noqa: E402
                                           load_checkpoint, load_weights, save_checkpoint)
 from distributedpytorch_amd.utils.checkpoint import run_dir  # noqa: E402
+from distributedpytorch_amd.utils import sanity  # noqa: E402
 
 
 def parse_args(argv=None):
@@ -91,6 +95,20 @@ def parse_args(argv=None):
     ap.add_argument("--max-iters", type=int, default=0, help="stop each epoch after N iterations (smoke runs)")
     ap.add_argument("--log-every", type=int, default=20)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: start N rank processes (one per GPU) from this command")
+    ap.add_argument("--data-path", choices=["auto", "gpu", "cpu"], default="auto",
+                    help="gpu: decoded uint8 dataset resident in HBM + one augmentation gather per step "
+                         "(data.gpu_pipeline); cpu: the reference's worker-side transforms (behaviour parity)")
+    ap.add_argument("--gpu-cache-gb", type=float, default=64.0, help="HBM budget of the device sample store; larger "
+                    "datasets stream raw uint8 batches one step ahead instead")
+    ap.add_argument("--sbd-root", default=None, help="SBD benchmark_RELEASE root for --use_sbd 1")
+    ap.add_argument("--hang-timeout", type=int, default=int(os.environ.get("DPAMD_HANG_DUMP_S", "0")),
+                    help="seconds without a finished log interval before every thread's stack is dumped and the "
+                         "rank exits (0 = off)")
+    ap.add_argument("--finite-every", type=int, default=50, help="steps between host reads of the device-side "
+                    "non-finite-loss flag")
+    ap.add_argument("--on-nonfinite", choices=["abort", "restore"], default="abort",
+                    help="restore: reload the last checkpoint of this run and continue (at most 3 times)")
     return ap.parse_args(argv)
 
 
@@ -121,13 +139,15 @@ def build_transforms(args, train: bool):
     return tr.Compose([tr.FixedScaleCenterCrop(args.crop), tr.Normalize(), tr.SemSegToTensor()])
 
 
-def build_datasets(args):
-    t_tr, t_ts = build_transforms(args, True), build_transforms(args, False)
+def build_datasets(args, raw: bool = False):
+    """``raw``: datasets without transforms (the GPU data path decodes on the host and augments on the device)."""
+    t_tr = None if raw else build_transforms(args, True)
+    t_ts = build_transforms(args, False)
     if args.synthetic:
         mode = "instance" if args.task == "instance" else "semantic"
-        raw = (args.crop, args.crop)
-        db_train = SyntheticVOC(args.synthetic_len, raw, t_tr, mode, seed=args.seed)
-        db_val = SyntheticVOC(max(args.synthetic_len // 8, 8), raw, t_ts, mode, seed=args.seed + 1)
+        size = (args.crop, args.crop)
+        db_train = SyntheticVOC(args.synthetic_len, size, t_tr, mode, seed=args.seed)
+        db_val = SyntheticVOC(max(args.synthetic_len // 8, 8), size, t_ts, mode, seed=args.seed + 1)
         return db_train, db_val
     root = args.data_root or os.environ.get("VOC_ROOT")
     if root is None:
@@ -136,9 +156,13 @@ def build_datasets(args):
     voc_train = VOCSegmentation(root=root, split="train", transform=t_tr, semantic=semantic, check_integrity=False)
     voc_val = VOCSegmentation(root=root, split="val", transform=t_ts, semantic=semantic, check_integrity=False)
     db_train = voc_train
-    if args.use_sbd:  # train_pascal.py:150-152 (the reference's SBD import is commented out)
-        raise SystemExit("SBD is not bundled; CombineDBs([voc_train, sbd], excluded=[voc_val]) is the hook")
-    _ = CombineDBs  # exported for that hook
+    if args.use_sbd:  # train_pascal.py:150-152: CombineDBs([voc_train, sbd], excluded=[voc_val])
+        from distributedpytorch_amd.data.sbd import SBDSegmentation
+        sbd_root = args.sbd_root or os.environ.get("SBD_ROOT")
+        if sbd_root is None:
+            raise SystemExit("--use_sbd 1 needs --sbd-root (or SBD_ROOT): the SBD benchmark_RELEASE directory")
+        sbd = SBDSegmentation(root=sbd_root, split=["train", "val"], transform=t_tr, semantic=semantic)
+        db_train = CombineDBs([voc_train, sbd], excluded=[voc_val])
     return db_train, voc_val
 
 
@@ -149,25 +173,65 @@ def _collate_keys(task):
 # --------------------------------------------------------------------------------------
 # train / validate (the reference's TODO "single fn train / single fn val")
 # --------------------------------------------------------------------------------------
-def train_epoch(engine, loader, sampler, scheduler, epoch, args, log):
-    sampler.set_epoch(epoch)
-    kin, kgt = _collate_keys(args.task)
+class StepGuard:
+    """Failure detection on the hot loop without host syncs: a device-side counter of
+    non-finite losses (read every ``every`` steps) and a hang watchdog that is re-armed whenever the loop makes
+    progress — if no step retires for ``hang_s`` seconds every thread's stack goes to stderr and the rank exits,
+    so a stuck collective names its call site instead of hanging the job."""
+
+    def __init__(self, device, every: int, hang_s: int):
+        self.bad = torch.zeros((), dtype=torch.int32, device=device)
+        self.every, self.hang_s, self.n = max(int(every), 1), int(hang_s), 0
+        self.device = device
+        if self.hang_s > 0:
+            import faulthandler
+            faulthandler.dump_traceback_later(self.hang_s, exit=True)
+
+    def step(self, loss: torch.Tensor, global_step: int) -> None:
+        self.bad += (~torch.isfinite(loss.detach())).to(torch.int32)      # device-side, no sync
+        self.n += 1
+        if self.n % self.every == 0:
+            self.check(global_step)
+
+    def check(self, global_step: int) -> None:
+        bad = float(self.bad.item())                                       # the one host read per interval
+        if self.hang_s > 0:
+            import faulthandler
+            faulthandler.dump_traceback_later(self.hang_s, exit=True)      # progress was made: re-arm
+        dev = self.device if self.device.type == "cuda" else None
+        if dist_env.all_reduce_scalar(bad, "max", dev) > 0:
+            self.bad.zero_()
+            raise FloatingPointError(f"non-finite loss within the {self.every} steps before step {global_step} "
+                                     "on at least one rank")
+
+    def close(self) -> None:
+        if self.hang_s > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+
+
+def train_epoch(engine, loader, scheduler, epoch, args, log, guard=None, checker=None):
+    """One epoch.  ``loader`` yields ``(inputs, target)`` — already augmented device tensors on the GPU data path,
+    host tensors from the DataLoader workers on the CPU path."""
+    loader.set_epoch(epoch)
     running = torch.zeros((), device=engine.device)
     n_iter, n_img = 0, 0
     t0 = timeit.default_timer()
     data_wait, t_fetch = 0.0, timeit.default_timer()
-    for ii, batch in enumerate(loader):
-        data_wait += timeit.default_timer() - t_fetch          # host time blocked on the loader workers
+    for ii, (inputs, gts) in enumerate(loader):
+        data_wait += timeit.default_timer() - t_fetch          # host time blocked on the data path
         if args.max_iters and ii >= args.max_iters:
             break
         scheduler(engine.optimizer, ii, epoch)
-        inputs, gts = batch[kin], batch[kgt]
+        if checker is not None:                                # DPAMD_DEBUG: the reference's per-batch asserts
+            checker.check(inputs, gts)
         loss = engine.train_step(inputs, gts)
         running += loss.float() * engine.accum_steps
         n_iter += 1
         n_img += inputs.shape[0]
+        if guard is not None:
+            guard.step(loss, engine.global_step)
         if args.log_every and (ii + 1) % args.log_every == 0:
-            dist_env.check_finite_or_abort(loss, engine.global_step)   # one host sync per log interval
             dt = timeit.default_timer() - t0
             extra = {}
             if engine.on_gpu:
@@ -177,15 +241,37 @@ def train_epoch(engine, loader, sampler, scheduler, epoch, args, log):
                     img_per_s=n_img * dist_env.get_world_size() / dt,
                     data_wait_ms=1e3 * data_wait / n_iter, **extra, **engine.timer.summary())
         t_fetch = timeit.default_timer()
+    if guard is not None:
+        guard.check(engine.global_step)
     mean_loss = dist_env.all_reduce_scalar(float(running) / max(n_iter, 1), "sum", engine.device
                                            if engine.on_gpu else None) / dist_env.get_world_size()
+    if engine.on_gpu:
+        torch.cuda.synchronize(engine.device)
     dt = timeit.default_timer() - t0
-    return mean_loss, n_img * dist_env.get_world_size() / max(dt, 1e-9)
+    return mean_loss, n_img * dist_env.get_world_size() / max(dt, 1e-9), 1e3 * data_wait / max(n_iter, 1)
+
+
+class HostLoader:
+    """The reference's data path: DataLoader workers run the CPU transforms; dict batches → (inputs, target)."""
+
+    def __init__(self, loader, sampler, kin, kgt):
+        self.loader, self.sampler, self.kin, self.kgt = loader, sampler, kin, kgt
+
+    def set_epoch(self, epoch):
+        self.sampler.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for b in self.loader:
+            yield b[self.kin], b[self.kgt]
 
 
 @torch.no_grad()
-def validate_instance(engine, loader, args):
-    """Per-object Jaccard at thresholds .3/.5/.8 with void pixels excluded (train_pascal.py:280-306)."""
+def validate_instance(engine, loader, args, epoch=0, fig_path=None):
+    """Per-object Jaccard at thresholds .3/.5/.8 with void pixels excluded (train_pascal.py:280-306); the first
+    batch's prediction and attention maps go to a 4-panel PNG (train_pascal.py:257-278)."""
     engine.model.eval()
     thresh = [0.3, 0.5, 0.8]
     jac = np.zeros(3)
@@ -197,7 +283,11 @@ def validate_instance(engine, loader, args):
         x = engine.prepare_input(batch["concat"])
         out = engine.model(x)
         loss_sum += float(engine.criterion(out, batch["crop_gt"].to(engine.device)))
-        pred = out[0] if isinstance(out, (tuple, list)) else out
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        pred = outs[0]
+        if ii == 0 and fig_path is not None and dist_env.is_master():
+            from distributedpytorch_amd.utils.visualize import save_validation_panels
+            save_validation_panels(fig_path, batch["concat"][0], batch["crop_gt"][0, 0], [o[0] for o in outs], epoch)
         for jj in range(pred.shape[0]):
             p = torch.sigmoid(pred[jj, 0].float()).cpu().numpy()
             gt = helpers.tens2image(batch["gt"][jj])
@@ -228,8 +318,40 @@ class _KeyLoader:
             yield b[self.kin], b[self.kgt]
 
 
+def _seed_worker(base_seed):
+    """DataLoader ``worker_init_fn``: NumPy's global generator (every CPU transform draws from it) seeded from
+    (seed, rank, worker id, torch's per-epoch worker seed) — without it worker w of EVERY rank replays the same
+    flips / scales / rotations (the reference has one process, so it never met this)."""
+    def init(worker_id):
+        info = torch.utils.data.get_worker_info()
+        ss = np.random.SeedSequence([base_seed, worker_id, int(info.seed) % (2 ** 32)])
+        np.random.seed(ss.generate_state(4))
+        import random
+        random.seed(int(ss.generate_state(1)[0]))
+    return init
+
+
+def _semseg_figure(engine, loader, fig_path, epoch):
+    """4-panel PNG of the first validation sample for the semantic task (prediction = arg-max class map)."""
+    from distributedpytorch_amd.utils.visualize import save_validation_panels
+    engine.model.eval()
+    with torch.no_grad():
+        for images, target in loader:
+            out = engine.model(engine.prepare_input(images[:1]))
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            save_validation_panels(fig_path, images[0], target[0], [o[0] for o in outs], epoch, semantic=True)
+            return
+
+
 def main(argv=None):
     args = parse_args(argv)
+    # ---- one command, N GPUs (the reference's `train_pascal.py:92`): launch the ranks before any GPU call ----
+    from distributedpytorch_amd.parallel.launch import maybe_self_launch
+    status = maybe_self_launch(args.gpus, argv=argv, script=os.path.abspath(__file__), cpu=args.device == "cpu")
+    if status is not None:
+        if status:
+            sys.exit(status)
+        return None
     instance = args.task == "instance"
     args.crop = args.crop or (512 if instance else 513)
     args.lr = args.lr if args.lr is not None else (5e-8 if instance else 0.007)
@@ -237,12 +359,18 @@ def main(argv=None):
     args.model = args.model or ("danet_resnet101" if instance else "deeplabv3plus_resnet101")
     args.nInputChannels = args.nInputChannels or (4 if instance else 3)
     info = init_distributed(device="cpu" if args.device == "cpu" else None)
+    if args.gpus > 1 and info.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the job has WORLD_SIZE={info.world_size}")
     if args.impl == "stock":
         ops.set_backend("torch")
-    if info.is_master and info.device.type == "cuda":
+    on_gpu = info.device.type == "cuda"
+    if info.is_master and on_gpu:
         print("Using GPU: {} ".format(info.device.index))
-    torch.manual_seed(args.seed)
+    torch.manual_seed(args.seed)                       # identical model init on every rank
     np.random.seed(args.seed * 1000 + info.rank)
+    data_path = args.data_path
+    if data_path == "auto":
+        data_path = "gpu" if on_gpu else "cpu"
 
     save_root = args.save_dir or os.path.dirname(os.path.abspath(__file__))
     save_dir = run_dir(save_root, args.resume_epoch)
@@ -261,17 +389,53 @@ def main(argv=None):
                          accum_steps=args.nAveGrad)
     if args.weights:
         load_weights(args.weights, engine.ddp, strict=False)
+    best_val = 0.0
+    last_ckpt = None
     if args.resume_epoch:
         ck = os.path.join(save_dir, "models", model_name + "_epoch-" + str(args.resume_epoch - 1) + ".pth")
-        print("Initializing weights from: {}".format(ck))
-        load_checkpoint(ck, engine.ddp, engine.optimizer)
+        if not os.path.isfile(ck):          # every rank checks the same path: all raise together, none is left waiting
+            raise FileNotFoundError(f"--resume_epoch {args.resume_epoch}: {ck} does not exist")
+        if info.is_master:
+            print("Initializing weights from: {}".format(ck))
+        extra = load_checkpoint(ck, engine.ddp, engine.optimizer)
+        # the sidecar carries what the reference keeps in a variable across epochs (train_pascal.py:177, :301-304):
+        # without it the first validation after a resume would overwrite <model>_best.pth with a worse model
+        best_val = float(extra.get("best_val", 0.0))
+        last_ckpt = ck
+        if info.is_master:
+            print("Resumed: epoch {} best_val {:.4f}".format(extra.get("epoch", args.resume_epoch - 1), best_val))
 
-    db_train, db_val = build_datasets(args)
-    sampler = DistributedSampler(len(db_train), shuffle=True, seed=args.seed, drop_last=True)
-    val_sampler = DistributedSampler(len(db_val), shuffle=False, drop_last=False)
-    pin = info.device.type == "cuda"
-    trainloader = DataLoader(db_train, batch_size=args.trainBatch, sampler=sampler, num_workers=args.workers,
-                             drop_last=True, pin_memory=pin, persistent_workers=args.workers > 0)
+    # ---- data ----
+    kin, kgt = _collate_keys(args.task)
+    pin = on_gpu
+    if data_path == "gpu":
+        from distributedpytorch_amd.data.gpu_pipeline import GpuBatchLoader
+        db_train, db_val = build_datasets(args, raw=True)
+        sampler = DistributedSampler(len(db_train), shuffle=True, seed=args.seed, drop_last=True)
+        rots, scales = ((-20, 20), (.75, 1.25)) if instance else ((0.0, 0.0), (0.5, 2.0))
+        trainloader = GpuBatchLoader(db_train, sampler, args.trainBatch, info.device, args.crop, args.task,
+                                     scales=scales, rots=rots, seed=args.seed, rank=info.rank, workers=args.workers,
+                                     hbm_budget_gb=args.gpu_cache_gb, relax=50, zero_pad=bool(args.zero_pad_crop))
+        t_start = timeit.default_timer()
+        trainloader.prepare()
+        if info.is_master and trainloader.store is not None:
+            print("Device sample store: {} samples, {:.2f} GiB, filled in {:.1f} s".format(
+                len(db_train), trainloader.store.nbytes / 2 ** 30, timeit.default_timer() - t_start))
+        train_tf = ["GPU: " + ("Flip+ScaleNRotate+CropFromMaskStatic+FixedResize+NEllipseWithGaussians+ConcatInputs"
+                               if instance else "RandomScaleCrop+Flip+Normalize") + " (ops.augment)"]
+    else:
+        db_train, db_val = build_datasets(args)
+        sampler = DistributedSampler(len(db_train), shuffle=True, seed=args.seed, drop_last=True)
+        gen = torch.Generator().manual_seed(args.seed * 1000 + info.rank)     # rank-dependent worker base seeds
+        loader = DataLoader(db_train, batch_size=args.trainBatch, sampler=sampler, num_workers=args.workers,
+                            drop_last=True, pin_memory=pin, persistent_workers=args.workers > 0, generator=gen,
+                            worker_init_fn=_seed_worker(args.seed * 1000 + info.rank))
+        trainloader = HostLoader(loader, sampler, kin, kgt)
+        tf = getattr(db_train, "transform", None) or getattr(getattr(db_train, "dataloaders", [None])[0],
+                                                            "transform", None)
+        train_tf = [str(t) for t in tf.transforms] if tf is not None else []
+    # evaluation visits every validation sample exactly once over all ranks (no wrap-around duplicates)
+    val_sampler = DistributedSampler(len(db_val), shuffle=False, drop_last=False, pad=False)
     test_bs = args.testBatch if instance else max(args.testBatch, 1)
     testloader = DataLoader(db_val, batch_size=test_bs, sampler=val_sampler, num_workers=args.workers,
                             pin_memory=pin)
@@ -282,42 +446,65 @@ def main(argv=None):
     p["trainBatch"], p["nAveGrad"], p["lr"], p["wd"], p["momentum"] = \
         args.trainBatch, args.nAveGrad, args.lr, args.wd, args.momentum
     p["world_size"], p["model"], p["task"], p["crop"] = info.world_size, args.model, args.task, args.crop
+    p["data_path"] = data_path
     p["optimizer"] = str(engine.optimizer)
     p["dataset_train"], p["dataset_test"] = str(db_train), str(db_val)
-    p["transformations_train"] = [str(t) for t in db_train.transform.transforms]
+    p["transformations_train"] = train_tf
     p["transformations_test"] = [str(t) for t in db_val.transform.transforms]
     p["host"], p["started"] = socket.gethostname(), datetime.now().strftime("%b%d_%H-%M-%S")
     if info.is_master:
         helpers.generate_param_report(os.path.join(save_dir, exp_name + ".txt"), p)
 
-    best_val = 0.0
-    kin, kgt = _collate_keys(args.task)
+    guard = StepGuard(info.device, args.finite_every, args.hang_timeout)
+    checker = sanity.BatchSanity(args.task, nclass, 255, normalised=not instance) if sanity.ENABLED else None
+    restores = 0
     if info.is_master:
         print("Training Network")
-    for epoch in range(args.resume_epoch, args.nEpochs):
+    epoch = args.resume_epoch
+    while epoch < args.nEpochs:
         start_time = timeit.default_timer()
         if info.is_master:
             print("Current LR", engine.optimizer.param_groups[0]["lr"])
-        tr_loss, ips = train_epoch(engine, trainloader, sampler, scheduler, epoch, args, log)
+        try:
+            tr_loss, ips, wait_ms = train_epoch(engine, trainloader, scheduler, epoch, args, log, guard, checker)
+        except FloatingPointError as e:
+            # every rank raised together (StepGuard all-reduces the flag).  "restore": go back to
+            # the last checkpoint this run wrote (weights, momentum, RNG) and redo the epoch — at most 3 times.
+            if args.on_nonfinite != "restore" or last_ckpt is None or restores >= 3:
+                raise
+            restores += 1
+            log.log("restore", epoch=epoch, reason=str(e), checkpoint=last_ckpt, attempt=restores)
+            extra = load_checkpoint(last_ckpt, engine.ddp, engine.optimizer)
+            engine.ddp.arena.zero_grad()
+            best_val = float(extra.get("best_val", best_val))
+            np.random.seed(args.seed * 1000 + info.rank + 7919 * restores)     # do not replay the same batches
+            continue
         log.log("epoch", epoch=epoch, numImages=len(trainloader) * args.trainBatch * info.world_size,
-                loss=tr_loss, img_per_s=ips)
+                loss=tr_loss, img_per_s=ips, data_wait_ms=wait_ms)
         if (epoch % args.snapshot) == args.snapshot - 1 and epoch != 0:
-            save_checkpoint(os.path.join(save_dir, "models", model_name + "_epoch-" + str(epoch) + ".pth"),
-                            engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val})
+            last_ckpt = os.path.join(save_dir, "models", model_name + "_epoch-" + str(epoch) + ".pth")
+            save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val})
         if args.useTest and epoch % args.nTestInterval == (args.nTestInterval - 1):
+            fig = os.path.join(save_dir, "figures", "val_epoch-{}.png".format(epoch))
             if instance:
-                res = validate_instance(engine, testloader, args)
+                res = validate_instance(engine, testloader, args, epoch, fig)
                 score = max(res["jaccard"])
                 log.log("val", epoch=epoch, loss=res["loss"], JACCARD=res["jaccard"])
             else:
                 res = engine.evaluate(_KeyLoader(testloader, kin, kgt, args.max_iters), 21, 255)
                 score = res["miou"]
                 log.log("val", epoch=epoch, loss=res["loss"], mIoU=res["miou"], pixel_acc=res["pixel_acc"])
+                if info.is_master:
+                    _semseg_figure(engine, _KeyLoader(testloader, kin, kgt, 1), fig, epoch)
             if score > best_val:
                 best_val = score
-                save_checkpoint(os.path.join(save_dir, "models", model_name + "_best.pth"), engine.ddp,
-                                engine.optimizer, {"epoch": epoch, "best_val": best_val})
+                last_ckpt = os.path.join(save_dir, "models", model_name + "_best.pth")
+                save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val})
             log.log("time", epoch=epoch, execution_time=timeit.default_timer() - start_time)
+        epoch += 1
+    guard.close()
+    if checker is not None:
+        checker.raise_if_flagged()
     save_checkpoint(os.path.join(save_dir, "models", model_name + "_last.pth"), engine.ddp, engine.optimizer,
                     {"epoch": args.nEpochs - 1, "best_val": best_val})
     log.close()
