@@ -19,7 +19,7 @@ bucketed gradient all-reduce → fused SGD.  Weak scaling: per-GPU batch is fixe
 
 ``--impl stock`` measures the stock PyTorch-ROCm path (MIOpen conv / ATen BN) on the same model
 code — the self-established baseline of BASELINE.md; ``--impl native`` (default) runs the
-hand-written HIP kernels.  The stock numbers live in ``profiles/self_baseline.json`` (written by
+hand-written HIP kernels.  The stock numbers live in ``bench_baseline.json`` (written by
 ``--record-baseline``); the ratio reported beside the (null) ``vs_baseline`` is EQUAL-BATCH.
 """
 from __future__ import annotations
@@ -32,7 +32,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-BASELINE_FILE = os.path.join(ROOT, "profiles", "self_baseline.json")
+BASELINE_FILE = os.path.join(ROOT, "bench_baseline.json")   # not under profiles/: that directory is not shipped to GPU runs
 
 
 def parse_args():
@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU/gloo (tiny shapes)")
     ap.add_argument("--phases", action="store_true", help="print per-phase HIP-event timings (rank 0)")
     ap.add_argument("--record-baseline", action="store_true",
-                    help="with --impl stock: store this run in profiles/self_baseline.json")
+                    help="with --impl stock: store this run in bench_baseline.json")
     ap.add_argument("--source-log", default=None, help="log file name recorded with --record-baseline")
     return ap.parse_args()
 
@@ -98,6 +98,16 @@ def main():
     if os.environ.get("DPAMD_HANG_DUMP_S"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DPAMD_HANG_DUMP_S"]), exit=True)
+    if os.environ.get("DPAMD_HEARTBEAT_S"):
+        # long silent phases (MIOpen's kernel search on the stock path, first-step autotuning): one line a minute
+        import threading
+        t_start = time.time()
+
+        def beat():
+            while True:
+                time.sleep(float(os.environ["DPAMD_HEARTBEAT_S"]))
+                print(f"[bench] alive, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
+        threading.Thread(target=beat, daemon=True).start()
     import numpy as np
     import torch
     from distributedpytorch_amd import ops

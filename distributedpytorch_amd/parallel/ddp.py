@@ -163,7 +163,7 @@ class DistributedDataParallel(nn.Module):
         if not _COMM_STREAM:
             return None
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=device, priority=-1)
+            self._comm_stream = torch.cuda.Stream(device=device)      # only event waits (+ staged copies under gloo) run here
         return self._comm_stream
 
     def _collective(self, g: torch.Tensor) -> None:
