@@ -181,8 +181,10 @@ class GpuBatchLoader:
             self.store.fill(self.raw, self.workers, label_fill=self.label_fill, progress=progress)
 
     # ------------------------------------------------------------------
-    def _augment(self, images, labels, src_idx, sizes_dev, sizes_host):
+    def _augment(self, images, labels, src_idx, sizes_dev, sizes_host, idx_host=None):
         bsz = len(sizes_host)
+        # validate the HOST copies; the device path then launches without reading anything back (no host sync)
+        ops.augment.check_slots(idx_host, sizes_host, images.shape[0], images.shape[1:3])
         out = (self.crop, self.crop)
         self.steps += 1
         if self.task == "semseg":
@@ -197,7 +199,8 @@ class GpuBatchLoader:
             m = torch.from_numpy(mats)
             if self.device.type == "cuda":
                 m = m.pin_memory().to(self.device, non_blocking=True)
-            return ops.affine_augment2(images, labels, m, out, src_idx, sizes_dev, out_dtype=self.out_dtype)
+            return ops.affine_augment2(images, labels, m, out, src_idx, sizes_dev, out_dtype=self.out_dtype,
+                                       validated=True)
         warp = ops.make_warp_params(bsz, sizes_host, self.rots, self.scales, self.flip_p if self.train else 0.0,
                                     self.rng) if self.train else \
             np.tile(np.array([1, 0, 0, 0, 1, 0], dtype=np.float32), (bsz, 1))
@@ -206,7 +209,7 @@ class GpuBatchLoader:
             w = w.pin_memory().to(self.device, non_blocking=True)
         x, y, _ = ops.instance_augment(images, labels, src_idx, sizes_dev, w, out, self.relax, self.zero_pad,
                                        random_points=self.train, seed=int(self.rng.integers(0, 2 ** 31 - 1)),
-                                       out_dtype=self.out_dtype)
+                                       out_dtype=self.out_dtype, validated=True)
         return x, y
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
@@ -226,7 +229,7 @@ class GpuBatchLoader:
                 src = src.pin_memory().to(self.device, non_blocking=True)
             sizes_host = st.sizes_host[idx]
             sizes_dev = st.sizes.index_select(0, src.long()) if self.device.type == "cuda" else st.sizes[idx]
-            yield self._augment(st.images, st.labels, src, sizes_dev, sizes_host)
+            yield self._augment(st.images, st.labels, src, sizes_dev, sizes_host, idx)
 
     def _iter_stream(self):
         on_gpu = self.device.type == "cuda"

@@ -261,7 +261,7 @@ def _i32(t, shape, name, device):
 
 
 def affine_augment2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, interp, lab_fill, clamp, mean, std,
-                    border, channels, out_dtype):
+                    border, channels, out_dtype, validated=False):
     import ctypes
     if out_dtype != torch.bfloat16:
         raise TypeError("HIP augmentation writes bf16")
@@ -281,16 +281,19 @@ def affine_augment2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, interp
     if lab_u8 is not None and (lab_u8.dtype != torch.uint8 or tuple(lab_u8.shape) != (nslots, hi, wi)
                                or not lab_u8.is_contiguous() or lab_u8.device != dev):
         raise ValueError("label store must be contiguous uint8 [N,H,W] on the image store's device")
-    # host-side range checks of what the kernel will index with (a bad slot / size is an out-of-bounds read)
-    if src_idx is not None:
-        lo, hi_ = int(src_idx.min()), int(src_idx.max())
-        if lo < 0 or hi_ >= nslots:
-            raise IndexError(f"src_idx outside the store: [{lo}, {hi_}] vs {nslots} slots")
-    elif bsz != nslots:
+    # range checks of what the kernel will index with (a bad slot / size is an out-of-bounds read).  ``validated``:
+    # the caller checked its HOST copies of src_idx / sizes (ops.augment.check_slots) — reading the device tensors
+    # here costs a host sync per step (measured: 82 ms of "data wait" per B128 step in train_pascal.py)
+    if src_idx is None and bsz != nslots:
         raise ValueError("without src_idx the store must hold exactly the batch")
-    if sizes is not None:
-        if int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi:
-            raise ValueError("sizes outside the slot dimensions")
+    if not validated:
+        if src_idx is not None:
+            lo, hi_ = int(src_idx.min()), int(src_idx.max())
+            if lo < 0 or hi_ >= nslots:
+                raise IndexError(f"src_idx outside the store: [{lo}, {hi_}] vs {nslots} slots")
+        if sizes is not None:
+            if int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi:
+                raise ValueError("sizes outside the slot dimensions")
     cout = max(3, int(channels))
     out = torch.empty((bsz, ho, wo, cout), dtype=torch.bfloat16, device=dev)
     out_lab = torch.empty((bsz, ho, wo), dtype=torch.uint8, device=dev) if lab_u8 is not None else None
@@ -302,7 +305,7 @@ def affine_augment2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, interp
     return out.permute(0, 3, 1, 2), out_lab
 
 
-def mask_bbox(mask_u8, src_idx, sizes, mats):
+def mask_bbox(mask_u8, src_idx, sizes, mats, validated=False):
     if mask_u8.dtype != torch.uint8 or mask_u8.dim() != 3 or not mask_u8.is_contiguous():
         raise ValueError("mask_bbox: contiguous uint8 [N,H,W]")
     nslots, hi, wi = mask_u8.shape
@@ -311,13 +314,13 @@ def mask_bbox(mask_u8, src_idx, sizes, mats):
     mats = mats.to(device=dev, dtype=torch.float32).contiguous()
     src_idx = _i32(src_idx, (bsz,), "src_idx", dev)
     sizes = _i32(sizes, (bsz, 2), "sizes", dev)
-    if src_idx is not None:
-        if int(src_idx.min()) < 0 or int(src_idx.max()) >= nslots:
-            raise IndexError("src_idx outside the store")
-    elif bsz != nslots:
+    if src_idx is None and bsz != nslots:
         raise ValueError("without src_idx the store must hold exactly the batch")
-    if sizes is not None and (int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi):
-        raise ValueError("sizes outside the slot dimensions")
+    if not validated:
+        if src_idx is not None and (int(src_idx.min()) < 0 or int(src_idx.max()) >= nslots):
+            raise IndexError("src_idx outside the store")
+        if sizes is not None and (int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi):
+            raise ValueError("sizes outside the slot dimensions")
     bbox = torch.empty((bsz, 4), dtype=torch.int32, device=dev)
     B.check(_lib().dp_mask_bbox(B.ptr(mask_u8), B.ptr(src_idx), B.ptr(sizes), B.ptr(mats), B.ptr(bbox), bsz, hi, wi,
                                 B.stream_ptr()), "mask_bbox")

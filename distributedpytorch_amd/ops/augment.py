@@ -161,7 +161,7 @@ def affine_augment2(img_u8: torch.Tensor, lab_u8: Optional[torch.Tensor], mats: 
                     interp: str = "bilinear", lab_fill: int = 255, clamp: bool = False,
                     mean: Sequence[float] = IMAGENET_MEAN, std: Sequence[float] = IMAGENET_STD,
                     border: Optional[Sequence[float]] = None, channels: int = 3,
-                    out_dtype: torch.dtype = torch.bfloat16):
+                    out_dtype: torch.dtype = torch.bfloat16, validated: bool = False):
     """General inverse-affine gather over a (possibly padded, device-resident) uint8 sample store.
 
     ``img_u8`` [N,H,W,3], ``lab_u8`` [N,H,W] or None; ``mats`` [B,6] out→source maps; ``src_idx`` int32 [B] slot of
@@ -180,7 +180,7 @@ def affine_augment2(img_u8: torch.Tensor, lab_u8: Optional[torch.Tensor], mats: 
     if B.use_hip(img_u8):
         from . import _hip_misc
         return _hip_misc.affine_augment2(img_u8, lab_u8, src_idx, sizes, mats, clip, out_size, ip, lab_fill,
-                                         clamp, mean, std, border, channels, out_dtype)
+                                         clamp, mean, std, border, channels, out_dtype, validated)
     out, lab = _reference_affine2(img_u8, lab_u8, src_idx, sizes, mats.float(), clip, out_size, ip, lab_fill, clamp,
                                   mean, std, border, channels)
     return out.to(out_dtype).contiguous(memory_format=torch.channels_last), lab
@@ -213,12 +213,23 @@ def make_warp_params(batch: int, sizes, rots: Tuple[float, float] = (-20.0, 20.0
 
 
 @torch.no_grad()
-def mask_bbox(mask_u8: torch.Tensor, mats: torch.Tensor, src_idx=None, sizes=None) -> torch.Tensor:
+def check_slots(src_idx_host, sizes_host, nslots: int, slot_hw) -> None:
+    """Host-side validation of slot indices / valid sizes (NumPy copies) — lets the device path skip its own
+    checks, which would read device tensors and synchronise the host with the GPU every step."""
+    if src_idx_host is not None and len(src_idx_host) and (min(src_idx_host) < 0 or max(src_idx_host) >= nslots):
+        raise IndexError(f"src_idx outside the store ({nslots} slots)")
+    if sizes_host is not None and len(sizes_host):
+        sz = np.asarray(sizes_host)
+        if sz.min() < 1 or sz[:, 0].max() > slot_hw[0] or sz[:, 1].max() > slot_hw[1]:
+            raise ValueError("sizes outside the slot dimensions")
+
+
+def mask_bbox(mask_u8: torch.Tensor, mats: torch.Tensor, src_idx=None, sizes=None, validated: bool = False) -> torch.Tensor:
     """int32 [B,4] inclusive (x_min, y_min, x_max, y_max) of the nearest-warped mask on its canvas; (·,·,−1,−1) when
     empty — ``helpers.get_bbox`` of ``ScaleNRotate``'s output (`/root/reference/custom_transforms.py:359`)."""
     if B.use_hip(mask_u8):
         from . import _hip_misc
-        return _hip_misc.mask_bbox(mask_u8, src_idx, sizes, mats)
+        return _hip_misc.mask_bbox(mask_u8, src_idx, sizes, mats, validated)
     Bn = mats.shape[0]
     out = torch.empty(Bn, 4, dtype=torch.int32)
     for b in range(Bn):
@@ -333,7 +344,7 @@ def nellipse_guidance_(out: torch.Tensor, pts: torch.Tensor, channel: int = 3, a
 def instance_augment(img_u8: torch.Tensor, gt_u8: torch.Tensor, src_idx: torch.Tensor, sizes: torch.Tensor,
                      warp_mats: torch.Tensor, out_size: Tuple[int, int] = (512, 512), relax: int = 50,
                      zero_pad: bool = True, alpha: float = 0.6, random_points: bool = True, seed: int = 0,
-                     out_dtype: torch.dtype = torch.bfloat16):
+                     out_dtype: torch.dtype = torch.bfloat16, validated: bool = False):
     """The reference's whole training transform chain for the instance task
     (`/root/reference/train_pascal.py:123-134`) on the device: Flip → ScaleNRotate (``warp_mats``) →
     CropFromMaskStatic(relax, zero_pad) → FixedResize(out_size) → NEllipseWithGaussians(alpha) →
@@ -341,11 +352,11 @@ def instance_augment(img_u8: torch.Tensor, gt_u8: torch.Tensor, src_idx: torch.T
     them; crop_gt [B,1,Ho,Wo] float {0,1}; crop_bbox int32 [B,4])``.  ONE bicubic resampling replaces the
     reference's two (warp, then resize): fewer interpolation passes, same geometry."""
     warp_mats = warp_mats.to(img_u8.device)
-    bbox = mask_bbox(gt_u8, warp_mats, src_idx, sizes)
+    bbox = mask_bbox(gt_u8, warp_mats, src_idx, sizes, validated)
     mats, clip, crop_bbox = compose_crop(warp_mats, bbox, out_size, relax, zero_pad, sizes, tuple(img_u8.shape[1:3]))
     x, crop_gt = affine_augment2(img_u8, gt_u8, mats, out_size, src_idx, sizes, clip, interp="bicubic", lab_fill=0,
                                  clamp=True, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), border=(0.0, 0.0, 0.0),
-                                 channels=4, out_dtype=out_dtype)
+                                 channels=4, out_dtype=out_dtype, validated=validated)
     pts = extreme_points(crop_gt, random_points, seed)
     nellipse_guidance_(x, pts, 3, alpha)
     return x, crop_gt.unsqueeze(1).to(torch.float32), crop_bbox
