@@ -5,8 +5,9 @@ call sites: ``forward`` returns a 3-tuple ``(fused, position_branch, channel_bra
 input resolution (`:258-260` visualises ``[1]`` / ``[2]`` as the position / channel attention
 outputs, ``[0]`` is the prediction used for Jaccard, `:283`).
 
-Attention matmuls are plain batched GEMMs (hipBLASLt through ``torch.bmm``); the convolutions, BN
-and resizes run the hand-written kernels.
+The attention modules run fused hand-written kernels on the GPU (``ops.attention`` / csrc/attention.hip:
+flash-style position attention that never materialises the (H·W)² map, gram + softmax + per-image 1×1
+convolutions for the channel attention), like the convolutions, BN and resizes.
 """
 from __future__ import annotations
 
@@ -15,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops import conv_bn_act, BatchNorm2d, Conv2d, bilinear_resize
+from ..ops.attention import channel_attention, position_attention
 from .resnet import ResNet
 
 
@@ -29,13 +31,7 @@ class PositionAttention(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
 
     def forward(self, x):
-        n, c, h, w = x.shape
-        q = self.query_conv(x).reshape(n, -1, h * w).transpose(1, 2)   # [n, hw, c/8]
-        k = self.key_conv(x).reshape(n, -1, h * w)                    # [n, c/8, hw]
-        attn = torch.softmax(torch.bmm(q, k).float(), dim=-1).to(x.dtype)  # [n, hw, hw]
-        v = self.value_conv(x).reshape(n, c, h * w)                   # [n, c, hw]
-        out = torch.bmm(v, attn.transpose(1, 2)).reshape(n, c, h, w)
-        return self.gamma.to(x.dtype) * out + x
+        return position_attention(self.query_conv(x), self.key_conv(x), self.value_conv(x), x, self.gamma)
 
 
 class ChannelAttention(nn.Module):
@@ -46,13 +42,7 @@ class ChannelAttention(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
 
     def forward(self, x):
-        n, c, h, w = x.shape
-        f = x.reshape(n, c, h * w)
-        energy = torch.bmm(f, f.transpose(1, 2)).float()               # [n, c, c]
-        energy = energy.max(dim=-1, keepdim=True)[0] - energy
-        attn = torch.softmax(energy, dim=-1).to(x.dtype)
-        out = torch.bmm(attn, f).reshape(n, c, h, w)
-        return self.gamma.to(x.dtype) * out + x
+        return channel_attention(x, self.gamma)
 
 
 class _ConvBNReLU(nn.Module):

@@ -56,7 +56,7 @@ def _round8(c: int) -> int:
 def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
           pad: Tuple[int, int], dil: Tuple[int, int], bias: Optional[torch.Tensor] = None,
           stats: Optional[torch.Tensor] = None, tile: int = 0, cfg: Optional[int] = None,
-          residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw kernel call.  ``x`` [N,Cin,Hi,Wi] channels-last bf16; ``w_krsc`` logical [Cout,Cin,R,S]
     stored channels-last (memory [Cout][R][S][Cin]).  Returns [N,Cout,Ho,Wo] channels-last bf16.
     ``residual`` (same shape/layout as the result) is added in the kernel's store loop."""
@@ -71,7 +71,14 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
     if not (w_krsc.permute(0, 2, 3, 1).is_contiguous()):
         raise ValueError("igemm: weights must be stored [Cout][R][S][Cin]")
     ho, wo = out_hw
-    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    if out is not None:
+        # caller-provided destination (e.g. one image's slice of a batch tensor: per-image weights, ops.attention)
+        if (out.dtype != torch.bfloat16 or tuple(out.shape) != (n, cout, ho, wo) or out.device != x.device
+                or not out.is_contiguous(memory_format=torch.channels_last) or out.data_ptr() % 16):
+            raise ValueError("igemm: out must be a 16-byte aligned channels-last bf16 tensor of the result's shape")
+        y = out
+    else:
+        y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != cout):
         raise ValueError("igemm: bias must be fp32[Cout]")
     reps = 1
