@@ -44,7 +44,10 @@ def parse_args():
                     help="per-GPU batch (128 x 513² holds 55 GiB of the 288 GB HBM3E)")
     ap.add_argument("--crop", type=int, default=513)
     ap.add_argument("--model", default="deeplabv3plus_resnet101")
-    ap.add_argument("--in-channels", type=int, default=3)
+    ap.add_argument("--in-channels", type=int, default=None, help="default: 3 (semseg) / 4 (instance)")
+    ap.add_argument("--task", choices=["semseg", "instance"], default="semseg",
+                    help="instance: the reference's own workload (`train_pascal.py:86`, `:123-134`) — DANet, 4-channel "
+                         "RGB + n-ellipse guidance input, binary object mask, the whole transform chain on the GPU")
     ap.add_argument("--output-stride", type=int, default=None)
     ap.add_argument("--impl", choices=["native", "stock"], default=os.environ.get("DPAMD_BENCH_IMPL", "native"))
     ap.add_argument("--sync-bn", action="store_true")
@@ -126,10 +129,18 @@ def main():
         raise SystemExit(f"[bench] --impl native but DPAMD_BACKEND={ops.get_backend()!r} forces the PyTorch ops; "
                          "unset it or pass --impl stock")
     torch.manual_seed(1234)  # identical init on every rank; DDP broadcasts anyway
-    nclass = 21
+    instance = args.task == "instance"
+    if args.in_channels is None:
+        args.in_channels = 4 if instance else 3
+    nclass = 1 if instance else 21
     model = build_model(args.model, nclass, output_stride=args.output_stride, sync_bn=args.sync_bn,
                         in_channels=args.in_channels)
-    engine = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.007, momentum=0.9, weight_decay=5e-4,
+    if instance:
+        from distributedpytorch_amd.utils import SegmentationMultiLosses
+        criterion = SegmentationMultiLosses(1)
+    else:
+        criterion = SoftmaxCrossEntropy(255)
+    engine = TrainEngine(model, criterion, lr=5e-8 if instance else 0.007, momentum=0.9, weight_decay=5e-4,
                          device=info.device, bucket_mb=args.bucket_mb)
     B, S = args.batch, args.crop
     g = torch.Generator().manual_seed(100 + info.rank)
@@ -144,7 +155,30 @@ def main():
     if args.in_channels > 3:        # RGB + guidance channels (the instance task's 4-channel input)
         extra_ch = torch.rand(B, args.in_channels - 3, S, S, generator=g).to(info.device)
 
+    if instance:
+        # one object per image (an ellipse of random size / position): the binary masks of the instance task
+        yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+        cy = torch.randint(S // 4, 3 * S // 4, (B, 1, 1), generator=g)
+        cx = torch.randint(S // 4, 3 * S // 4, (B, 1, 1), generator=g)
+        ry = torch.randint(S // 10, S // 4, (B, 1, 1), generator=g)
+        rx = torch.randint(S // 10, S // 4, (B, 1, 1), generator=g)
+        gt_mask = ((((yy - cy).float() / ry) ** 2 + ((xx - cx).float() / rx) ** 2) <= 1.0).to(torch.uint8)
+        gt_mask = gt_mask.contiguous().to(info.device)
+        slot_idx = torch.arange(B, dtype=torch.int32, device=info.device)
+        sizes_host = np.full((B, 2), S, dtype=np.int32)
+        sizes_dev = torch.from_numpy(sizes_host).to(info.device)
+        from distributedpytorch_amd.ops import instance_augment, make_warp_params
+
     def one_step():
+        if instance:
+            # the reference's transform chain (flip, scale+rotate, mask crop, resize, guidance map, concat) on device
+            warp = make_warp_params(B, sizes_host, (-20, 20), (.75, 1.25), 0.5, rng)
+            with engine.timer.phase("augment"):
+                x, y, _ = instance_augment(raw_img, gt_mask, slot_idx, sizes_dev,
+                                           torch.from_numpy(warp).to(info.device, non_blocking=True), (S, S), 50, True,
+                                           seed=int(rng.integers(0, 2 ** 31 - 1)), out_dtype=engine.compute_dtype,
+                                           validated=True)
+            return engine.train_step(x, y)
         mats = make_affine_params(B, (S, S), (S, S), scales=(0.5, 2.0), flip_p=0.5, rng=rng)
         with engine.timer.phase("augment"):
             x, y = affine_augment(raw_img, raw_lab, torch.from_numpy(mats).to(info.device, non_blocking=True),
@@ -185,7 +219,8 @@ def main():
             print("[bench] phases(ms):", {k: round(v, 3) for k, v in phases.items()}, file=sys.stderr)
             if on_gpu:
                 print(f"[bench] peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
-        headline = args.model == "deeplabv3plus_resnet101" and args.crop == 513 and args.in_channels == 3
+        headline = (args.model == "deeplabv3plus_resnet101" and args.crop == 513 and args.in_channels == 3
+                    and not instance)
         rec = {
             "metric": ("train images/sec (node) DeepLabv3+ R101 513x513" if headline
                        else f"train images/sec (node) {args.model} {args.crop}x{args.crop}"),
@@ -195,7 +230,7 @@ def main():
             "dtype": "bf16" if on_gpu else "fp32", "data": "synthetic",
             "config": {"model": args.model, "global_batch": world * B, "per_gpu_batch": B,
                        "seq_len": S, "crop": S, "num_classes": nclass, "in_channels": args.in_channels,
-                       "parallelism": f"dp{world}", "impl": args.impl, "sync_bn": bool(args.sync_bn),
+                       "task": args.task, "parallelism": f"dp{world}", "impl": args.impl, "sync_bn": bool(args.sync_bn),
                        "optimizer": "sgd-momentum", "final_loss": round(final_loss, 4)},
             "comm": {"backend": info.backend, "rccl_world": world if info.backend == "nccl" else 0,
                      "devices": devices, "buckets": len(engine.ddp.arena.buckets), "bucket_mb": args.bucket_mb,

@@ -14,6 +14,8 @@ FAMILIES = [
     ("dpamd conv wgrad", r"conv_wgrad"),
     ("dpamd conv fwd/dgrad igemm", r"dp_conv|igemm_kernel|conv_igemm"),
     ("dpamd batchnorm", r"bn_stats_kernel|bn_apply_kernel|bn_bwd"),
+    ("dpamd attention", r"pam_|cam_"),
+    ("dpamd data path", r"affine_augment|mask_bbox|compose_crop|extreme_points|nellipse"),
     ("dpamd misc", r"dp_|softmax_ce|upsample_ce|bilinear_|maxpool|avgpool|sgd_flat|affine_aug|confusion|dwconv|weight_transpose|pad_channels|p2p_"),
     ("MIOpen batchnorm", r"MIOpenBatchNorm"),
     ("upsample (ATen)", r"upsample_bilinear"),
