@@ -459,6 +459,115 @@ inline dim3 grid_reduce(long M, int C) {
     return dim3((unsigned)splits, (unsigned)slabs, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm folded into the 1x1 convolution that consumes it (Xception's depthwise -> BN -> pointwise:
+// no activation in between, so  W (s*z + t) = (W diag(s)) z + W t  and the normalised tensor never exists).
+//   bn_fold      stats of z -> s = gamma*rstd, mean, rstd, running statistics; W' = W diag(s) (bf16);
+//                b' = W t (the constant the next BatchNorm cancels; its running mean is corrected for it)
+//   bn_fold_bwd  dW'(fp32, from the weight-gradient kernel run on raw z) -> dW += dW' diag(s),
+//                ds_j = sum_k dW'_kj W_kj ; then c_j = -ds_j gamma_j rstd_j^3 / M (dz = W'^T dy + c (z - mean)),
+//                dgamma_j += ds_j rstd_j
+// ------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    const float* stats; int nrep; long rep_stride;       // [nrep][2][Cin] partial sums of z, z^2
+    const float* gamma; const float* beta;               // [Cin] (null: 1 / 0)
+    float* rmean; float* rvar;                           // running statistics of the folded BN (or null)
+    float inv_count, eps, momentum, unbias;
+    const bf16_raw* w; bf16_raw* wf;                     // [Cout][Cin]
+    float* s_out; float* mean_out; float* rstd_out;      // [Cin]
+    float* bprime;                                       // [Cout] = W t
+    float* rmean2; float rm2_scale;                      // next BN's running mean += rm2_scale * b' (or null)
+    int Cout, Cin;
+};
+
+__global__ __launch_bounds__(256) void bn_fold_kernel(FoldArgs a) {
+    extern __shared__ float fold_sh[];                   // s[Cin], t[Cin], red[256]
+    float* s_sh = fold_sh;
+    float* t_sh = fold_sh + a.Cin;
+    float* red = fold_sh + 2 * a.Cin;
+    for (int j = threadIdx.x; j < a.Cin; j += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < a.nrep; ++r) {
+            s1 += a.stats[r * a.rep_stride + j];
+            s2 += a.stats[r * a.rep_stride + a.Cin + j];
+        }
+        const float mean = s1 * a.inv_count;
+        const float var = fmaxf(fmaf(-mean, mean, s2 * a.inv_count), 0.f);
+        const float rstd = rsqrtf(var + a.eps);
+        const float sc = (a.gamma ? a.gamma[j] : 1.f) * rstd;
+        s_sh[j] = sc;
+        t_sh[j] = fmaf(-mean, sc, a.beta ? a.beta[j] : 0.f);
+        if (blockIdx.x == 0) {
+            a.s_out[j] = sc; a.mean_out[j] = mean; a.rstd_out[j] = rstd;
+            if (a.rmean) {
+                a.rmean[j] = fmaf(a.momentum, mean - a.rmean[j], a.rmean[j]);
+                a.rvar[j] = fmaf(a.momentum, var * a.unbias - a.rvar[j], a.rvar[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = blockIdx.x; k < a.Cout; k += gridDim.x) {
+        const bf16_raw* wr = a.w + (long)k * a.Cin;
+        bf16_raw* wo = a.wf + (long)k * a.Cin;
+        float acc = 0.f;
+        for (int j8 = threadIdx.x * 8; j8 < a.Cin; j8 += 256 * 8) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(wr + j8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc = fmaf(f[j], t_sh[j8 + j], acc);
+                f[j] *= s_sh[j8 + j];
+            }
+            *reinterpret_cast<uint4*>(wo + j8) = pack8(f);
+        }
+        acc = wave_sum(acc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float bp = red[0] + red[1] + red[2] + red[3];
+            a.bprime[k] = bp;
+            if (a.rmean2) a.rmean2[k] += a.rm2_scale * bp;
+        }
+    }
+}
+
+// 64 x 64 tile of the weight matrix per block: dW_sink += dW' * s (columns), ds[j] += sum_k dW'_kj W_kj
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restrict__ dwf, const bf16_raw* __restrict__ w,
+                                                          const float* __restrict__ s, float* __restrict__ dw_sink,
+                                                          float* __restrict__ ds, int Cout, int Cin, float sink_scale) {
+    __shared__ float part[4][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int k0 = blockIdx.y * 64;
+    float acc = 0.f;
+    if (j < Cin) {
+        const float sj = s[j] * sink_scale;
+        for (int k = k0 + rl; k < min(k0 + 64, Cout); k += 4) {
+            const long idx = (long)k * Cin + j;
+            const float g = dwf[idx];
+            acc = fmaf(g, bf2f(w[idx]), acc);
+            dw_sink[idx] += g * sj;
+        }
+    }
+    part[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && j < Cin) atomicAdd(ds + j, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// c_j = -ds_j gamma_j rstd_j^3 / M ; shift_j = -c_j mean_j ; dgamma_sink_j += ds_j rstd_j * sink_scale
+__global__ void bn_fold_bwd_final_kernel(const float* __restrict__ ds, const float* __restrict__ gamma,
+                                         const float* __restrict__ rstd, const float* __restrict__ mean,
+                                         float* __restrict__ cvec, float* __restrict__ cshift,
+                                         float* __restrict__ dgamma_sink, float inv_count, float sink_scale, int Cin) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Cin) return;
+    const float g = gamma ? gamma[j] : 1.f, r = rstd[j];
+    const float c = -ds[j] * g * r * r * r * inv_count;
+    cvec[j] = c;
+    cshift[j] = -c * mean[j];
+    if (dgamma_sink) dgamma_sink[j] += ds[j] * r * sink_scale;
+}
+
 // set by dp_bn_set_dropout for the NEXT apply_stats / bwd_reduce / bwd_apply launch of this thread
 thread_local Drop t_drop = {0u, 1.f, 0u, 0u};
 
@@ -599,5 +708,37 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
     a.dy_ld8 = ld8_;
     if ((mask_mode == 3 && a.drop.thr == 0) || a.dy_ld8 * 8 < C || ((uintptr_t)dy & 15)) return -1;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid_for(M, C, 4), block_for(C), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}
+
+// Fold the BatchNorm described by `stats` (partial sums of z, z^2 over `count` rows) into the [Cout][Cin] bf16
+// weights of the 1x1 convolution that consumes it.  s/mean/rstd: fp32 [Cin] outputs; bprime fp32 [Cout].
+DP_EXPORT int dp_bn_fold(const float* stats, int nrep, long rep_stride, const float* gamma, const float* beta,
+                         float* rmean, float* rvar, float count, float eps, float momentum, const void* w, void* wf,
+                         float* s_out, float* mean_out, float* rstd_out, float* bprime, float* rmean2,
+                         float rm2_scale, int Cout, int Cin, hipStream_t st) {
+    if (!stats || !w || !wf || !s_out || !mean_out || !rstd_out || !bprime || nrep < 1 || Cin <= 0 || Cout <= 0 ||
+        Cin % 8 != 0 || Cin > 8192 || count <= 0.f)
+        return -1;
+    if (((uintptr_t)w | (uintptr_t)wf) & 15) return -3;
+    FoldArgs a{stats, nrep, rep_stride, gamma, beta, rmean, rvar, 1.f / count, eps, momentum,
+               count > 1.f ? count / (count - 1.f) : 1.f, (const bf16_raw*)w, (bf16_raw*)wf, s_out, mean_out,
+               rstd_out, bprime, rmean2, rm2_scale, Cout, Cin};
+    const int blocks = Cout < 512 ? Cout : 512;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(blocks), dim3(256), (size_t)(2 * Cin + 256) * sizeof(float), st, a);
+    return DP_LAUNCH_STATUS();
+}
+
+// dwf fp32 [Cout][Cin] (weight gradient w.r.t. the folded weights); dw_sink fp32 [Cout][Cin] accumulated;
+// ds fp32 [Cin] zero-initialised scratch; cvec / cshift fp32 [Cin] outputs; dgamma_sink fp32 [Cin] accumulated or null
+DP_EXPORT int dp_bn_fold_bwd(const float* dwf, const void* w, const float* s, const float* gamma, const float* rstd,
+                             const float* mean, float* dw_sink, float* ds, float* cvec, float* cshift,
+                             float* dgamma_sink, float count, float sink_scale, int Cout, int Cin, hipStream_t st) {
+    if (!dwf || !w || !s || !rstd || !mean || !dw_sink || !ds || !cvec || !cshift || Cin <= 0 || Cout <= 0 || count <= 0.f)
+        return -1;
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64), dim3(256), 0, st, dwf,
+                       (const bf16_raw*)w, s, dw_sink, ds, Cout, Cin, sink_scale);
+    hipLaunchKernelGGL(bn_fold_bwd_final_kernel, dim3((Cin + 255) / 256), dim3(256), 0, st, ds, gamma, rstd, mean, cvec,
+                       cshift, dgamma_sink, 1.f / count, sink_scale, Cin);
     return DP_LAUNCH_STATUS();
 }

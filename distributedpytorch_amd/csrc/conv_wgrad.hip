@@ -498,7 +498,14 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     static const int force_g = getenv("DPAMD_WGRAD_G") ? atoi(getenv("DPAMD_WGRAD_G")) : 0;
     const long x_bytes0 = (long)N * Hi * Wi * ldx * 2;
     const bool gen2_ok = !(reserved == 1 || x_bytes0 >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24));
-    const int G = (gen2_ok && Cout % (2 * TM) == 0 && force_g != 1) ? 2 : 1;
+    // G = 2 also for channel counts that do not fill the last 256-channel block (Xception's 728 = 2.84 x 256): the
+    // kernel's loads and its combine are bounds-checked per 128-channel sub-tile, and what the ragged block wastes
+    // (768 vs 728 rows) the shared x tile and the 3-deep ring pay back many times — the 4-wave G = 1 kernel ran the
+    // 728 -> 728 pointwise layers at 232 TFLOP/s (profiles/r2_x65_os8_b64_v28_profile.md).  Not when the padding to
+    // 256 would add more than 1/8 to the rows the 128-blocks cover.
+    const int pad256 = (Cout + 2 * TM - 1) / (2 * TM) * (2 * TM), pad128 = (Cout + TM - 1) / TM * TM;
+    const bool g2_shape = Cout > TM && pad256 * 8 <= pad128 * 9;
+    const int G = (gen2_ok && g2_shape && force_g != 1) ? 2 : 1;
     p.tiles_k = (Cout + TM * G - 1) / (TM * G);
     p.tiles_n = (p.NF + TN - 1) / TN;
     const int tiles = p.tiles_k * p.tiles_n;

@@ -345,7 +345,8 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil, runner=None) -> int:
     _TUNE_COUNTS["measured_here"] += 1
     lib, stream = _lib(), B.stream_ptr()
     # blocks own 256 output channels when Cout fills them (csrc/conv_wgrad.hip, G = 2), else 128
-    tk = 256 if (cout % 256 == 0 and os.environ.get("DPAMD_WGRAD_G") != "1") else 128
+    pad256, pad128 = (cout + 255) // 256 * 256, (cout + 127) // 128 * 128
+    tk = 256 if (cout > 128 and pad256 * 8 <= pad128 * 9 and os.environ.get("DPAMD_WGRAD_G") != "1") else 128
     tiles = ((cout + tk - 1) // tk) * ((r * s * cin + 127) // 128)
     steps_total = (n * ho * wo + 63) // 64
     cands = [0]
