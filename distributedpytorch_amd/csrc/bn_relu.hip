@@ -463,7 +463,7 @@ inline dim3 grid_reduce(long M, int C) {
 // BatchNorm folded into the 1x1 convolution that consumes it (Xception's depthwise -> BN -> pointwise:
 // no activation in between, so  W (s*z + t) = (W diag(s)) z + W t  and the normalised tensor never exists).
 //   bn_fold      stats of z -> s = gamma*rstd, mean, rstd, running statistics; W' = W diag(s) (bf16);
-//                b' = W t (the constant the next BatchNorm cancels; its running mean is corrected for it)
+//                b' = W beta - W' mean (the constant the next BatchNorm cancels; its running mean is corrected for it)
 //   bn_fold_bwd  dW'(fp32, from the weight-gradient kernel run on raw z) -> dW += dW' diag(s),
 //                ds_j = sum_k dW'_kj W_kj ; then c_j = -ds_j gamma_j rstd_j^3 / M (dz = W'^T dy + c (z - mean)),
 //                dgamma_j += ds_j rstd_j
@@ -481,10 +481,11 @@ struct FoldArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_fold_kernel(FoldArgs a) {
-    extern __shared__ float fold_sh[];                   // s[Cin], t[Cin], red[256]
+    extern __shared__ float fold_sh[];                   // s[Cin], beta[Cin], mean[Cin], red[4]
     float* s_sh = fold_sh;
-    float* t_sh = fold_sh + a.Cin;
-    float* red = fold_sh + 2 * a.Cin;
+    float* b_sh = fold_sh + a.Cin;
+    float* m_sh = fold_sh + 2 * a.Cin;
+    float* red = fold_sh + 3 * a.Cin;
     for (int j = threadIdx.x; j < a.Cin; j += 256) {
         float s1 = 0.f, s2 = 0.f;
         for (int r = 0; r < a.nrep; ++r) {
@@ -496,7 +497,8 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(FoldArgs a) {
         const float rstd = rsqrtf(var + a.eps);
         const float sc = (a.gamma ? a.gamma[j] : 1.f) * rstd;
         s_sh[j] = sc;
-        t_sh[j] = fmaf(-mean, sc, a.beta ? a.beta[j] : 0.f);
+        b_sh[j] = a.beta ? a.beta[j] : 0.f;
+        m_sh[j] = mean;
         if (blockIdx.x == 0) {
             a.s_out[j] = sc; a.mean_out[j] = mean; a.rstd_out[j] = rstd;
             if (a.rmean) {
@@ -511,14 +513,20 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(FoldArgs a) {
         bf16_raw* wo = a.wf + (long)k * a.Cin;
         float acc = 0.f;
         for (int j8 = threadIdx.x * 8; j8 < a.Cin; j8 += 256 * 8) {
-            float f[8];
+            // b' = sum_j W_kj beta_j - W'_kj mean_j with the ROUNDED W' the GEMM will use: mean(W' z) + b' is then
+            // the exact mean of the unfolded layer's output (the running mean of the next BN relies on it)
+            float f[8], g[8];
             unpack8(*reinterpret_cast<const uint4*>(wr + j8), f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                acc = fmaf(f[j], t_sh[j8 + j], acc);
+                acc = fmaf(f[j], b_sh[j8 + j], acc);
                 f[j] *= s_sh[j8 + j];
             }
-            *reinterpret_cast<uint4*>(wo + j8) = pack8(f);
+            const uint4 packed = pack8(f);
+            unpack8(packed, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(-g[j], m_sh[j8 + j], acc);
+            *reinterpret_cast<uint4*>(wo + j8) = packed;
         }
         acc = wave_sum(acc);
         __syncthreads();
@@ -725,7 +733,7 @@ DP_EXPORT int dp_bn_fold(const float* stats, int nrep, long rep_stride, const fl
                count > 1.f ? count / (count - 1.f) : 1.f, (const bf16_raw*)w, (bf16_raw*)wf, s_out, mean_out,
                rstd_out, bprime, rmean2, rm2_scale, Cout, Cin};
     const int blocks = Cout < 512 ? Cout : 512;
-    hipLaunchKernelGGL(bn_fold_kernel, dim3(blocks), dim3(256), (size_t)(2 * Cin + 256) * sizeof(float), st, a);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(blocks), dim3(256), (size_t)(3 * Cin + 8) * sizeof(float), st, a);
     return DP_LAUNCH_STATUS();
 }
 

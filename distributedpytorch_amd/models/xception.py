@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ..ops import conv_bn_act, BatchNorm2d, Conv2d
+from ..ops.sepconv import sepconv_bn_act
 
 
 class SeparableConv2d(nn.Module):
@@ -44,8 +45,9 @@ class _Unit(nn.Module):
         self.relu_after = relu_after
 
     def forward(self, x, residual=None, relu=None):
-        return conv_bn_act(self.sep.pointwise, self.bn, self.sep.depthwise_bn(x),
-                           relu=self.relu_after if relu is None else relu, residual=residual)
+        # (GPU training path: the depthwise BatchNorm is folded into the pointwise weights, ops.sepconv)
+        return sepconv_bn_act(self.sep, self.bn, x, relu=self.relu_after if relu is None else relu,
+                              residual=residual)
 
 
 class XceptionBlock(nn.Module):
@@ -138,7 +140,7 @@ class AlignedXception(nn.Module):
         x = self.block3(x)
         x = self.middle(x)
         x = self.block20(x)
-        x = conv_bn_act(self.conv3.pointwise, self.bn3, self.conv3.depthwise_bn(x), relu=True)
-        x = conv_bn_act(self.conv4.pointwise, self.bn4, self.conv4.depthwise_bn(x), relu=True)
-        x = conv_bn_act(self.conv5.pointwise, self.bn5, self.conv5.depthwise_bn(x), relu=True)
+        x = sepconv_bn_act(self.conv3, self.bn3, x, relu=True)
+        x = sepconv_bn_act(self.conv4, self.bn4, x, relu=True)
+        x = sepconv_bn_act(self.conv5, self.bn5, x, relu=True)
         return x, low

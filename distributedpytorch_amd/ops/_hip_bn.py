@@ -29,6 +29,9 @@ def _lib():
         lib.dp_bn_set_ld.argtypes = [c_long]
         lib.dp_bn_set_sum_replicas.argtypes = [c_int, c_long]
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
+        lib.dp_bn_fold.argtypes = [c_void_p, c_int, c_long] + [c_void_p] * 4 + [c_float] * 3 + [c_void_p] * 7 + \
+            [c_float, c_int, c_int, c_void_p]
+        lib.dp_bn_fold_bwd.argtypes = [c_void_p] * 11 + [c_float, c_float, c_int, c_int, c_void_p]
         _sigs_done = True
     return lib
 
@@ -219,3 +222,65 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
                                    B.ptr(gb_sink), B.ptr(lsdy), B.ptr(lsdyx), float(sink_scale), B.stream_ptr()),
             "bn_bwd_apply")
     return dx, dres
+
+
+def fold_into_pointwise(stats, weight, bias, running_mean, running_var, count, eps, momentum, w_lowp,
+                        next_running_mean=None, next_momentum=0.0):
+    """BatchNorm (training statistics ``stats`` = fp32 [R, 2, Cin] partial sums over ``count`` rows) folded
+    into the bf16 [Cout, Cin, 1, 1] weights of the 1x1 convolution that consumes it.  Returns
+    (w_folded bf16 KRSC, vec fp32 [3, Cin] = scale | mean | rstd, bprime fp32 [Cout] = W @ shift).
+    ``next_running_mean``: the FOLLOWING BatchNorm's running mean, pre-corrected for the constant ``bprime``
+    that BN will not see (its own update then lands on the exact value)."""
+    cout, cin = w_lowp.shape[:2]
+    if w_lowp.dtype != torch.bfloat16 or tuple(w_lowp.shape[2:]) != (1, 1) or cin % 8 or \
+            not w_lowp.permute(0, 2, 3, 1).is_contiguous():
+        raise ValueError("fold: weights must be bf16 [Cout, Cin, 1, 1] with Cin % 8 == 0")
+    if stats.dtype != torch.float32 or stats.dim() != 3 or tuple(stats.shape[1:]) != (2, cin) or \
+            not stats.is_contiguous():
+        raise ValueError("fold: stats must be contiguous fp32 [R, 2, Cin]")
+    for t, nm in ((weight, "weight"), (bias, "bias"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _check_vec(t, cin, nm)
+    _check_vec(next_running_mean, cout, "next_running_mean")
+    if next_running_mean is not None and not (0.0 <= next_momentum < 1.0):
+        raise ValueError("fold: the following BatchNorm's momentum must be in [0, 1)")
+    dev = w_lowp.device
+    wf = torch.empty((cout, cin, 1, 1), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    vec = torch.empty(3, cin, dtype=torch.float32, device=dev)
+    bprime = torch.empty(cout, dtype=torch.float32, device=dev)
+    rm2_scale = next_momentum / (1.0 - next_momentum) if next_running_mean is not None else 0.0
+    B.check(_lib().dp_bn_fold(B.ptr(stats), int(stats.shape[0]), 2 * cin, B.ptr(weight), B.ptr(bias),
+                              B.ptr(running_mean), B.ptr(running_var), float(count), float(eps), float(momentum),
+                              B.ptr(w_lowp), B.ptr(wf), B.ptr(vec[0]), B.ptr(vec[1]), B.ptr(vec[2]), B.ptr(bprime),
+                              B.ptr(next_running_mean), float(rm2_scale), cout, cin, B.stream_ptr()), "bn_fold")
+    return wf, vec, bprime
+
+
+def fold_backward(dwf, w_lowp, vec, weight, dw_sink, dgamma_sink, count, sink_scale=1.0):
+    """Backward of ``fold_into_pointwise``: ``dwf`` fp32 [Cout, Cin, 1, 1] (KRSC) is the gradient w.r.t. the
+    FOLDED weights.  Adds dW = dwf * scale into ``dw_sink`` and d(gamma) into ``dgamma_sink``; returns
+    cc fp32 [2, Cin] = (c, -c * mean) with dz = W'^T dy + c * z + (-c * mean)."""
+    cout, cin = w_lowp.shape[:2]
+    for t, nm in ((dwf, "dwf"), (dw_sink, "dw_sink")):
+        if t.dtype != torch.float32 or tuple(t.shape) != (cout, cin, 1, 1) or not t.permute(0, 2, 3, 1).is_contiguous():
+            raise ValueError(f"fold_backward: {nm} must be fp32 [Cout, Cin, 1, 1] stored KRSC")
+    if vec.dtype != torch.float32 or tuple(vec.shape) != (3, cin) or not vec.is_contiguous():
+        raise ValueError("fold_backward: vec must be fp32 [3, Cin]")
+    _check_vec(weight, cin, "weight"); _check_vec(dgamma_sink, cin, "dgamma_sink")
+    ds = workspace.zeros(cin, w_lowp.device)
+    cc = torch.empty(2, cin, dtype=torch.float32, device=w_lowp.device)
+    B.check(_lib().dp_bn_fold_bwd(B.ptr(dwf), B.ptr(w_lowp), B.ptr(vec[0]), B.ptr(weight), B.ptr(vec[2]),
+                                  B.ptr(vec[1]), B.ptr(dw_sink), B.ptr(ds), B.ptr(cc[0]), B.ptr(cc[1]),
+                                  B.ptr(dgamma_sink), float(count), float(sink_scale), cout, cin, B.stream_ptr()),
+            "bn_fold_bwd")
+    return cc
+
+
+def affine_add_(acc, x, scale, shift):
+    """acc += x * scale + shift (per channel), in place on the channels-last bf16 tensor ``acc``."""
+    _check_act(x, "x")
+    _check_act(acc, "acc", x)
+    M, C = _mc(x)
+    _check_vec(scale, C, "scale"); _check_vec(shift, C, "shift")
+    B.check(_lib().dp_bn_apply_affine(B.ptr(x), B.ptr(acc), B.ptr(acc), M, C, B.ptr(scale), B.ptr(shift), 0,
+                                      B.stream_ptr()), "bn_apply_affine")
+    return acc

@@ -1,0 +1,143 @@
+"""Separable-convolution unit ``depthwise 3x3 -> BN -> pointwise 1x1 -> BN (+residual)(+ReLU)`` with the inner
+BatchNorm folded into the pointwise weights.
+
+SURVEY.md §2.5 K13 / BASELINE.json config 5 (DeepLabv3+ Xception-65, output stride 8).  The reference reaches this
+unit only through its external model (`/root/reference/train_pascal.py:86`: ``backbone='xception'``); what it
+lowers to on MI355X is decided here.
+
+Xception's separable unit has NO activation between the depthwise BatchNorm and the pointwise convolution, so
+
+    pointwise(BN1(z)) = W (s * z + t) = (W diag(s)) z + W t,      s = gamma1 * rstd1,  t = beta1 - mean1 * s
+
+and the constant ``W t`` is cancelled by the BatchNorm that follows.  The folded path therefore never writes or
+reads the normalised tensor: the depthwise kernel's epilogue leaves the statistics of ``z``, a [Cout x Cin] kernel
+scales the weights, the MFMA implicit-GEMM consumes the raw ``z``.  Per unit and direction that removes one full
+read+write pass over the (728-channel, stride-8) activation in forward and two in backward (the measured profile
+of the unfused path: profiles/r2_x65_os8_b64_v28_profile.md, BatchNorm kernels 121 of 307 ms).
+
+Backward, with dW' the weight gradient w.r.t. the folded weights (computed by the ordinary weight-gradient kernel
+on the raw z) and M = N*H*W:
+
+    dW      = dW' diag(s)
+    ds_j    = sum_k dW'_kj W_kj            dgamma1_j = ds_j * rstd_j          dbeta1 = 0 (exactly: BN2 cancels it)
+    dz      = W'^T dy + c * (z - mean1),    c_j = -ds_j * gamma1_j * rstd_j^3 / M
+
+(the second term is the gradient through rstd1; the gradient through mean1 vanishes for the same reason dbeta1
+does).  The following BatchNorm's running mean is corrected for the constant it does not see.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from . import _backend as B
+from .conv import conv_bn_act
+
+_FOLD = os.environ.get("DPAMD_SEPCONV_FOLD", "1") != "0"
+
+
+def _sink_of(p):
+    s = getattr(p, "_dpamd_grad_sink", None)
+    if s is not None and p.grad is not None and p.grad.data_ptr() == s.data_ptr():
+        return s
+    return None
+
+
+class _FoldedPointwise(torch.autograd.Function):
+    """y', stats(y') = (W diag(s)) z with s from the statistics of z.  Inputs 1-3 are differentiable."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, weight, stats1, w_lowp, bn1, bn2):
+        from . import _hip_bn, _hip_conv, workspace
+        n, cin, h, w = z.shape
+        cout = weight.shape[0]
+        count = float(n * h * w)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        wf, vec, _ = _hip_bn.fold_into_pointwise(stats1, g32, b32, bn1.running_mean, bn1.running_var, count, bn1.eps,
+                                                 bn1.momentum, w_lowp, bn2.running_mean, bn2.momentum)
+        reps = _hip_conv.stat_replicas(n * h * w)
+        stats2 = workspace.zeros(reps * 2 * cout, z.device).view(reps, 2, cout)
+        y = _hip_conv.igemm(z, wf, (h, w), 1, 1, (0, 0), (1, 1), None, stats2)
+        ctx.save_for_backward(z, wf, w_lowp, vec, g32)
+        ctx.params = (gamma, beta, weight)
+        ctx.count = count
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(stats2)
+        return y, stats2
+
+    @staticmethod
+    def backward(ctx, dy, _unused=None):
+        if dy is None:
+            return (None,) * 8
+        from . import _hip_bn, _hip_conv, streams
+        z, wf, w_lowp, vec, g32 = ctx.saved_tensors
+        gamma, beta, weight = ctx.params
+        cout, cin = wf.shape[:2]
+        n, _, h, w = z.shape
+        dy = _hip_bn.as_nhwc(dy)
+        # weight gradient w.r.t. the folded weights: beside the data gradient, on the auxiliary stream
+        dwf = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=z.device,
+                          memory_format=torch.channels_last).zero_()
+        aux = None
+        if streams.enabled():
+            aux = streams.fork(z.device)
+            with torch.cuda.stream(aux):
+                _hip_conv.wgrad(dy, z, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=dwf)
+            dy.record_stream(aux)
+            z.record_stream(aux)
+            dwf.record_stream(aux)
+        else:
+            _hip_conv.wgrad(dy, z, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=dwf)
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = _hip_conv.igemm(dy, _hip_conv.weight_transpose(wf), (h, w), 1, 1, (0, 0), (1, 1))
+        if aux is not None:
+            torch.cuda.current_stream(z.device).wait_stream(aux)
+        w_sink = _sink_of(weight) if ctx.needs_input_grad[3] else None
+        g_sink = _sink_of(gamma) if ctx.needs_input_grad[1] else None
+        dw = dgamma = dbeta = None
+        if w_sink is None:
+            dw = torch.zeros_like(dwf)
+        if g_sink is None:
+            dgamma = torch.zeros(cin, dtype=torch.float32, device=z.device)
+        cc = _hip_bn.fold_backward(dwf, w_lowp, vec, g32, w_sink if w_sink is not None else dw,
+                                   g_sink if g_sink is not None else dgamma, ctx.count)
+        if dz is not None:
+            _hip_bn.affine_add_(dz, z, cc[0], cc[1])
+        if ctx.needs_input_grad[2] and _sink_of(beta) is None:
+            dbeta = torch.zeros(cin, dtype=beta.dtype, device=z.device)
+        if dgamma is not None:
+            dgamma = dgamma.to(gamma.dtype) if ctx.needs_input_grad[1] else None
+        if dw is not None and not ctx.needs_input_grad[3]:
+            dw = None
+        for prm, grad_here in ((weight, dw), (gamma, dgamma), (beta, dbeta)):
+            if grad_here is None:
+                notify = getattr(prm, "_dpamd_on_grad", None)
+                if notify is not None and prm.requires_grad:
+                    notify(prm)
+        return dz, dgamma, dbeta, dw, None, None, None, None
+
+
+def can_fold(sep, bn2, x: torch.Tensor) -> bool:
+    dw, bn1, pw = sep.conv1, sep.bn, sep.pointwise
+    return (_FOLD and B.use_hip(x) and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+            and bn1.training and not bn1.frozen and not bn1.sync
+            and bn2.training and not bn2.frozen and not bn2.sync and 0.0 <= bn2.momentum < 1.0
+            and dw.can_fuse_stats(x) and pw.bias is None and pw.groups == 1 and pw.kernel_size == (1, 1)
+            and pw.stride == (1, 1) and pw.padding == (0, 0)
+            and pw.in_channels % 8 == 0 and pw.out_channels % 8 == 0 and pw.in_channels <= 8192)
+
+
+def sepconv_bn_act(sep, bn2, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
+                   dropout: float = 0.0):
+    """``act(BN2(pointwise(BN1(depthwise(x)))) + residual)`` for a ``models.xception.SeparableConv2d`` ``sep``.
+    Training on the GPU path with local (non-synchronised, non-frozen) statistics folds BN1 into the pointwise
+    weights; everything else runs the ordinary composition."""
+    if not can_fold(sep, bn2, x):
+        return conv_bn_act(sep.pointwise, bn2, sep.depthwise_bn(x), relu=relu, residual=residual, dropout=dropout)
+    z, stats1 = sep.conv1(x, with_stats=True)
+    bn1, pw = sep.bn, sep.pointwise
+    y, stats2 = _FoldedPointwise.apply(z, bn1.weight, bn1.bias, pw.weight, stats1, pw.lowp_weight(x.dtype), bn1, bn2)
+    return bn2(y, relu=relu, residual=residual, stats=stats2, dropout=dropout)
