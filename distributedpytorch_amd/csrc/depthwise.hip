@@ -519,14 +519,256 @@ inline int launch_dw3(const void* in, const void* in2, const void* w9, void* out
     return DP_LAUNCH_STATUS();
 }
 
-static const int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 3;
+// ------------------------------------------------------------------------------------------------
+// Fourth generation: rolling row window.  The row tiles above re-read their 2d halo rows per tile (TH = 4 at
+// d = 2 on the 65-column maps: every element staged TWICE) and a block alternates "wait for the whole tile" /
+// "compute" with nothing in flight while it computes: 427 us for a 394 MB tensor, 2.7x its HBM time
+// (profiles/r2_x65_os8_b64_v29_profile.md).  Here a block walks DOWN one image (or one of `hsplit` horizontal
+// bands) for a 64-channel slab with a ring of NR = 2 TS + 2d rows in LDS: TS + 2d rows feed the TS output rows
+// of the current step while LDS-DMA brings the next TS rows in, so every element is fetched once (plus 2d rows
+// per band) and the fetch overlaps the arithmetic.  Ring rows are rowpx = ceil8(W + 2d) pixels wide so one
+// wave-instruction (8 pixels x 128 B) never crosses into the next ring slot.
+constexpr int kDw4K = 5;                // pixels per thread and step: TS * W <= 32 * kDw4K
+
+struct Dw4 {
+    const bf16_raw* in; const bf16_raw* in2; const bf16_raw* w9; void* out;
+    int N, C, H, W, dil, TS, NR, hsplit, rows_split, flip, rowpx;
+    unsigned in_bytes;
+    float* stats; int stat_reps;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
+    const uint4* ring = reinterpret_cast<const uint4*>(smem4);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.y * 64;
+    const int ncg = min(8, (p.C - c0) >> 3);
+    const int n = blockIdx.x / p.hsplit, hs = blockIdx.x - n * p.hsplit;
+    const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
+    const int d = p.dil, W = p.W, TS = p.TS, NR = p.NR;
+    const int cg = tid & 7, pl = tid >> 3;
+    const bool cg_ok = cg < ncg;
+    const int ipr = p.rowpx >> 3;        // wave-instructions per staged row
+    const int rowch = p.rowpx * 8;       // 16-byte chunks per ring row
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const int c8 = lane & 7;
+    const unsigned img = (unsigned)(((long)n * p.H * W * p.C + c0 + c8 * 8) * 2);
+
+    // image rows r_first .. r_first + nrows - 1 -> their ring slots (rows outside the image, the horizontal
+    // padding and channel groups beyond C get an out-of-range offset: the buffer range check writes zeros)
+    auto stage = [&](int r_first, int nrows) {
+        for (int i = wave; i < nrows * ipr; i += 4) {
+            const int rr = i / ipr, seg = i - rr * ipr;
+            const int iy = r_first + rr;
+            const int slot = (iy - (ya - d)) % NR;
+            const int px = seg * 8 + (lane >> 3) - d;
+            const bool ok = (c8 < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)W);
+            const unsigned off = img + (unsigned)((iy * W + px) * p.C * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(smem4 + ((long)slot * rowch + seg * 64) * 16), 16,
+                ok ? off : kOOBd, 0, 0, 0);
+        }
+    };
+    const bf16_raw* in2 = MODE == 2 ? p.in2 + ((long)n * p.H * W) * p.C + c0 + cg * 8 : nullptr;
+    auto load_dy = [&](uint4 (&dq)[kDw4K], int y0) {
+        const int npix = min(TS, yb - y0) * W;
+#pragma unroll
+        for (int k = 0; k < kDw4K; ++k) {
+            const int pi = pl + 32 * k;
+            dq[k] = make_uint4(0, 0, 0, 0);
+            if (cg_ok && pi < npix) dq[k] = *reinterpret_cast<const uint4*>(in2 + ((long)y0 * W + pi) * p.C);
+        }
+    };
+
+    float w[MODE == 0 ? 9 : 1][8];
+    float acc2[MODE == 2 ? 9 : 1][8];
+    float s1[8], s2[8];
+    uint4 dq[kDw4K], dqn[kDw4K];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (cg_ok) unpack8(*reinterpret_cast<const uint4*>(p.w9 + (p.flip ? 8 - t : t) * p.C + c0 + cg * 8), w[t]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[t][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc2[t][j] = 0.f;
+        load_dy(dq, ya);
+    }
+    stage(ya - d, TS + 2 * d);
+    bf16_raw* outp = MODE == 0 ? reinterpret_cast<bf16_raw*>(p.out) + ((long)n * p.H * W) * p.C + c0 + cg * 8 : nullptr;
+
+    for (int y0 = ya; y0 < yb; y0 += TS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // this step's rows have landed; everyone is done with the rows about to be replaced
+        const bool more = y0 + TS < yb;
+        if (more) {
+            stage(y0 + TS + d, TS);
+            if (MODE == 2) load_dy(dqn, y0 + TS);
+        }
+        const int npix = min(TS, yb - y0) * W;
+        const int rbase = (y0 - ya) % NR;
+        int ry = pl / W, x = pl - ry * W;
+#pragma unroll
+        for (int k = 0; k < kDw4K; ++k) {
+            const int pi = pl + 32 * k;
+            if (pi < npix) {
+                int r0 = rbase + ry;  r0 -= r0 >= NR ? NR : 0;
+                int r1 = r0 + d;      r1 -= r1 >= NR ? NR : 0;
+                int r2 = r1 + d;      r2 -= r2 >= NR ? NR : 0;
+                const uint4* t0 = ring + r0 * rowch + x * 8 + cg;
+                const uint4* t1 = ring + r1 * rowch + x * 8 + cg;
+                const uint4* t2 = ring + r2 * rowch + x * 8 + cg;
+                uint4 v[9];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { v[q] = t0[q * d * 8]; v[3 + q] = t1[q * d * 8]; v[6 + q] = t2[q * d * 8]; }
+                if (MODE == 0) {
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        float xv[8];
+                        unpack8(v[t], xv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[t][j], acc[j]);
+                    }
+                    if (cg_ok) *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = pack8(acc);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
+                } else {
+                    float dv[8];
+                    unpack8(dq[k], dv);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        float xv[8];
+                        unpack8(v[t], xv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc2[t][j] = fmaf(dv[j], xv[j], acc2[t][j]);
+                    }
+                }
+            }
+            x += 32;
+            while (x >= W) { x -= W; ++ry; }
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < kDw4K; ++k) dq[k] = dqn[k];
+        }
+    }
+    __syncthreads();                                     // everyone is done with the ring
+    if (MODE == 0) {
+        if (p.stats) {                                   // uniform
+            float* red = reinterpret_cast<float*>(smem4);       // [32 pixel lanes][8 cg][16]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(pl * 8 + cg) * 16 + j] = s1[j];
+                red[(pl * 8 + cg) * 16 + 8 + j] = s2[j];
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int g = tid >> 4, e = tid & 15;
+                if (g < ncg) {
+                    float v = 0.f;
+#pragma unroll 8
+                    for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 16 + e];
+                    float* dst = p.stats + (long)(blockIdx.x % p.stat_reps) * 2 * p.C;
+                    atomicAdd(dst + (e >> 3) * p.C + c0 + g * 8 + (e & 7), v);
+                }
+            }
+        }
+    } else {
+        float* red = reinterpret_cast<float*>(smem4);           // [32 pixel lanes][8 cg][72]
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(pl * 8 + cg) * 72 + t * 8 + j] = acc2[t][j];
+        __syncthreads();
+        float* dw = reinterpret_cast<float*>(p.out);
+        for (int o = tid; o < 8 * 72; o += 256) {
+            const int g = o / 72, e = o - g * 72;
+            if (g >= ncg) continue;
+            float v = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 72 + e];
+            atomicAdd(dw + (e >> 3) * p.C + c0 + g * 8 + (e & 7), v);
+        }
+    }
+}
+
+template <int MODE>
+inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
+                      int flip, hipStream_t st, float* stats = nullptr, int stat_reps = 1) {
+    const long in_bytes = (long)N * H * W * C * 2;
+    if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
+    const int rowpx = (W + 2 * dil + 7) / 8 * 8;
+    const long row_bytes = (long)rowpx * 128;
+    int ts_max = (32 * kDw4K) / W;
+    if (ts_max > 4) ts_max = 4;
+    if (ts_max > H) ts_max = H;
+    if (ts_max < 1) return -2;
+    int TS = ts_max;                                    // two resident blocks per CU when a ring fits in 80 KiB
+    while (TS >= 1 && (2 * TS + 2 * dil) * row_bytes > 80 * 1024) --TS;
+    if (TS < 1) {
+        TS = ts_max;
+        while (TS >= 1 && (2 * TS + 2 * dil) * row_bytes > 160 * 1024) --TS;
+        if (TS < 1) return -2;
+    }
+    const int NR = 2 * TS + 2 * dil;
+    long lds = NR * row_bytes;
+    const int bpc = lds * 2 <= 160 * 1024 ? 2 : 1;
+    if (MODE == 2 && lds < 32 * 8 * 72 * 4) lds = 32 * 8 * 72 * 4;
+    if (MODE == 0 && stats && lds < 32 * 8 * 16 * 4) lds = 32 * 8 * 16 * 4;
+    if (lds > 160 * 1024) return -2;
+    // horizontal bands: the grid should fill whole rounds of the 256 x bpc resident block slots; a band costs its
+    // rows plus the 2d halo rows it re-reads
+    const long slabs = (C + 63) / 64, slots = 256L * bpc;
+    int best_hs = 1;
+    long best_cost = -1;
+    for (int hs = 1; hs <= 4; ++hs) {
+        const int rows = (H + hs - 1) / hs;
+        if (hs > 1 && rows < 2 * TS) break;
+        const long bands = (H + rows - 1) / rows;
+        const long rounds = (N * slabs * bands + slots - 1) / slots;
+        const long cost = rounds * (rows + 2 * dil);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_hs = hs; }
+    }
+    const int rows_split = (H + best_hs - 1) / best_hs;
+    const int hsplit = (H + rows_split - 1) / rows_split;
+    const long nb = (long)N * hsplit;
+    if (nb > 0x7fffffffL) return -4;
+    Dw4 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TS, NR, hsplit, rows_split,
+          flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps};
+    auto kfn = dwconv4_kernel<MODE>;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nb, (unsigned)slabs), dim3(256), (size_t)lds, st, p);
+    return DP_LAUNCH_STATUS();
+}
+
+// 4 = rolling row window (default), 3 = LDS row tiles, 2 / 1 = the strip / flat mappings
+static const int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 4;
 
 }  // namespace
 
 DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
                             int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
-    if (kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+    if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        if (kDwGen >= 4) {
+            const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st);
+            if (rc != -2) return rc;
+        }
         const int th = dw3_rows(Hi, Wi, dil, false);
         if (th > 0) {
             const int rc = launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st);
@@ -553,8 +795,12 @@ DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C
 DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N, int C, int Hi, int Wi, int Ho,
                                  int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
-    if (kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
-        const int th = dw3_rows(Hi, Wi, dil, false);                 // = forward over dy with the taps flipped
+    if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        if (kDwGen >= 4) {                                           // = forward over dy with the taps flipped
+            const int rc = launch_dw4<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, st);
+            if (rc != -2) return rc;
+        }
+        const int th = dw3_rows(Hi, Wi, dil, false);
         if (th > 0) {
             const int rc = launch_dw3<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, th, st);
             if (rc != -2) return rc;
@@ -577,7 +823,11 @@ DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N
 DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int N, int C, int Hi, int Wi, int Ho,
                                    int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
-    if (kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+    if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        if (kDwGen >= 4) {
+            const int rc = launch_dw4<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, st);
+            if (rc != -2) return rc;
+        }
         const int th = dw3_rows(Hi, Wi, dil, true);
         if (th > 0) {
             const int rc = launch_dw3<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, th, st);
@@ -613,7 +863,11 @@ DP_EXPORT int dp_dwconv_fwd_stats(const void* x, const void* w9, void* y, float*
                                   int Hi, int Wi, int Ho, int Wo, int stride, int pad_h, int pad_w, int dil,
                                   hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || !stats || stat_reps < 1) return -1;
-    if (!(kDwGen == 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi)) return -2;
+    if (!(kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi)) return -2;
+    if (kDwGen >= 4) {
+        const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st, stats, stat_reps);
+        if (rc != -2) return rc;
+    }
     const int th = dw3_rows(Hi, Wi, dil, false);
     if (th <= 0) return -2;
     return launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st, stats, stat_reps);

@@ -207,10 +207,12 @@ def test_wgrad_splits(case, splits):
 
 
 @pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
-@pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (1, 64, 7, 129)])
+@pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (1, 64, 7, 129), (1, 64, 9, 200),
+                                   (5, 64, 3, 5)])
 def test_depthwise(stride, dil, shape):
-    """flat kernels (stride 2) and the LDS row-tiled kernels (stride 1, several tiles per image,
-    partial 64-channel slab) against an fp32 CPU grouped convolution."""
+    """flat kernels (stride 2), the rolling-window kernels (stride 1: several bands per image, partial 64-channel
+    slab, one to four rows per step) and the row-tiled kernels behind them (maps wider than 160 columns) against
+    an fp32 CPU grouped convolution."""
     torch.manual_seed(1)
     n, c, h, w = shape
     x = _bf(torch.randn(n, c, h, w, device=DEV))

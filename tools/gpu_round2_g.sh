@@ -1,0 +1,5 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out/g
+timeout -k 10 400 python -u -m pytest tests/test_gpu_kernels.py tests/test_gpu_sepconv.py -x -q -k "depthwise or sepconv or folded" --timeout 120 --timeout-method thread 2>&1 | tee gpurun_out/g/tests.log | tail -8 &&
+DPAMD_HEARTBEAT_S=30 timeout -k 10 500 python -u bench.py --model deeplabv3plus_xception65 --output-stride 8 --batch 64 --steps 10 --warmup 4 --phases 2>&1 | tee gpurun_out/g/x65_b64_dw4.log | tail -4
