@@ -44,6 +44,8 @@ struct Conv2Args {
     float* stats;           // [stat_reps, 2, Cout] or null (never together with bias)
     const bf16_raw* res;    // [M, ldres] or null: added to the output in the store loop (the skip-path
     int ldres;              //   gradient of a residual block joins the data gradient here, no add kernel)
+    const float* res_scale; const float* res_shift;   // [Cout] or null: the store loop adds res * scale + shift
+                            //   (ops.sepconv: the statistics term of a folded BatchNorm's data gradient)
     // Fused BatchNorm+ReLU backward prologue (data-gradient launches only).  The tensor this kernel
     // differentiates, a = relu(BN(bnx) [+ identity]), is the previous layer's activation; instead of
     // da the store loop writes dm = da·[a > 0] and accumulates Σdm, Σdm·x̂ per channel — the two
@@ -432,6 +434,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         const int cpiece = tid % TPR, rsub = tid / TPR;
         const int gcol = n0 + cpiece * 8;
         if (p.bnx == nullptr) {
+            float rsc[8], rsh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool okc = p.res_scale != nullptr && gcol + j < p.Cout;
+                rsc[j] = okc ? p.res_scale[gcol + j] : 1.f;
+                rsh[j] = okc ? p.res_shift[gcol + j] : 0.f;
+            }
 #pragma unroll 4
             for (int r0 = 0; r0 < BM; r0 += RPP) {
                 const int row = r0 + rsub;
@@ -444,8 +453,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                         float a[8], b[8];
                         unpack8(o, a);
                         unpack8(*reinterpret_cast<const uint4*>(p.res + (long)m * p.ldres + gcol), b);
+                        if (p.res_scale) {               // uniform
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[j] += b[j];
+                            for (int j = 0; j < 8; ++j) a[j] += fmaf(b[j], rsc[j], rsh[j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) a[j] += b[j];
+                        }
                         o = pack8(a);
                     }
                     *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = o;
@@ -617,6 +631,7 @@ thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
 thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
+thread_local const float* t_res_affine[2] = {nullptr, nullptr};   // set by dp_conv_igemm2ra
 int g_ablate = 0;
 }  // namespace
 
@@ -642,6 +657,8 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     Conv2Args p{};
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.y = (bf16_raw*)y; p.bias = bias; p.stats = stats;
     p.res = (const bf16_raw*)res; p.ldres = ldres;
+    p.res_scale = res ? t_res_affine[0] : nullptr; p.res_shift = res ? t_res_affine[1] : nullptr;
+    if (p.res_scale && t_bnx) return -1;
     p.bnx = (const bf16_raw*)t_bnx; p.bna = (const bf16_raw*)t_bna; p.bnsums = t_bnsums;
     p.bn_mean = t_bnp[0]; p.bn_rstd = t_bnp[1]; p.bn_w = t_bnp[2]; p.bn_b = t_bnp[3];
     p.bn_reps = t_bn_reps < 1 ? 1 : t_bn_reps;
@@ -695,6 +712,19 @@ DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int 
                                    pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
     t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0;
     t_bnp[0] = t_bnp[1] = t_bnp[2] = t_bnp[3] = nullptr;
+    return rc;
+}
+
+// y = conv(x, w) + res * res_scale + res_shift (per output channel, fp32 [Cout] vectors) in the store loop
+DP_EXPORT int dp_conv_igemm2ra(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
+                               int Cout, int R, int S, int smul, int sdiv, int pad_h, int pad_w, int dil_h,
+                               int dil_w, int cfg, const void* res, const float* res_scale, const float* res_shift,
+                               hipStream_t st) {
+    if (!res || !res_scale || !res_shift) return -1;
+    t_res_affine[0] = res_scale; t_res_affine[1] = res_shift;
+    const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
+                                   pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
+    t_res_affine[0] = t_res_affine[1] = nullptr;
     return rc;
 }
 

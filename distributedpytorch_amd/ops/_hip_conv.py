@@ -32,6 +32,7 @@ def _lib():
         lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
         lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 8 + [I, V]
+        lib.dp_conv_igemm2ra.argtypes = [V, V, V] + [I] * 16 + [V] * 4
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -56,10 +57,12 @@ def _round8(c: int) -> int:
 def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
           pad: Tuple[int, int], dil: Tuple[int, int], bias: Optional[torch.Tensor] = None,
           stats: Optional[torch.Tensor] = None, tile: int = 0, cfg: Optional[int] = None,
-          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+          residual_affine: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw kernel call.  ``x`` [N,Cin,Hi,Wi] channels-last bf16; ``w_krsc`` logical [Cout,Cin,R,S]
     stored channels-last (memory [Cout][R][S][Cin]).  Returns [N,Cout,Ho,Wo] channels-last bf16.
-    ``residual`` (same shape/layout as the result) is added in the kernel's store loop."""
+    ``residual`` (same shape/layout as the result) is added in the kernel's store loop;
+    ``residual_affine`` (fp32 [2, Cout]: scale | shift) makes that ``residual * scale + shift``."""
     n, cin, hi, wi = x.shape
     cout, cin_w, r, s = w_krsc.shape
     if x.dtype != torch.bfloat16 or w_krsc.dtype != torch.bfloat16:
@@ -101,8 +104,16 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
         if (residual.dtype != torch.bfloat16 or residual.shape != y.shape or stats is not None
                 or not residual.is_contiguous(memory_format=torch.channels_last)):
             raise ValueError("igemm: residual must be a channels-last bf16 tensor of the output's shape (no stats)")
+    if residual_affine is not None:
+        ra = residual_affine
+        if residual is None or ra.dtype != torch.float32 or tuple(ra.shape) != (2, cout) or not ra.is_contiguous():
+            raise ValueError("igemm: residual_affine must be contiguous fp32 [2, Cout] next to a residual")
     if cfg > 0:
-        if residual is not None:
+        if residual_affine is not None:
+            st = _lib().dp_conv_igemm2ra(B.ptr(x), B.ptr(w_krsc), B.ptr(y), n, hi, wi, cin, ho, wo, cout, r, s, smul,
+                                         sdiv, pad[0], pad[1], dil[0], dil[1], cfg, B.ptr(residual),
+                                         B.ptr(residual_affine[0]), B.ptr(residual_affine[1]), B.stream_ptr())
+        elif residual is not None:
             st = _lib().dp_conv_igemm2r(*args, cfg, B.ptr(residual), cout, B.stream_ptr())
         else:
             st = _lib().dp_conv_igemm2(*args, cfg, B.stream_ptr())
@@ -110,6 +121,9 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
             B.check(st, "conv_igemm2")     # -4: tensor beyond its 32-bit offsets -> first-generation kernel
             return y
     B.check(_lib().dp_conv_igemm(*args, tile, B.stream_ptr()), "conv_igemm")
+    if residual_affine is not None:
+        from . import _hip_bn
+        return _hip_bn.affine_add_(y, residual, residual_affine[0], residual_affine[1])
     if residual is not None:
         y += residual
     return y
@@ -507,6 +521,7 @@ class _ConvIGemm(torch.autograd.Function):
 # filter ROW becomes one tap: the S*4 <= 32 contiguous elements to the right of a pixel are that
 # pixel's "channels" (overlapping windows, pixel stride ldx = 4).  7 taps of 32, second-generation
 # kernels for forward and weight gradient, fused BN statistics as everywhere else.
+_DW_WGRAD_AUX = os.environ.get("DPAMD_DW_WGRAD_AUX", "1") != "0"   # depthwise weight gradients on the aux stream
 _SKIP_WGRAD = os.environ.get("DPAMD_SKIP_WGRAD") == "1"     # diagnostics: invalid training, timing only
 _STEM_WINDOW = 32
 _STEM = os.environ.get("DPAMD_STEM_WINDOW", "1") != "0"
@@ -628,6 +643,7 @@ class _DepthwiseConv(torch.autograd.Function):
                                          padding[1], dilation[0], B.stream_ptr()), "dwconv_fwd")
         ctx.save_for_backward(x, w9)
         ctx.geom = (stride, padding, dilation, (hi, wi), (ho, wo))
+        ctx.weight_param = weight
         if with_stats:
             if stats is None:
                 from . import _hip_bn
@@ -652,10 +668,28 @@ class _DepthwiseConv(torch.autograd.Function):
                                               padding[0], padding[1], dilation[0], B.stream_ptr()), "dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
             dw9 = workspace.zeros(9 * c, x.device).view(9, c)
-            B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo, stride[0],
-                                                padding[0], padding[1], dilation[0], B.stream_ptr()),
-                    "dwconv_bwd_weight")
-            dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
+            wp = ctx.weight_param
+            sink = getattr(wp, "_dpamd_grad_sink", None)
+            if (sink is not None and wp.grad is not None and wp.grad.data_ptr() == sink.data_ptr()
+                    and streams.enabled() and _DW_WGRAD_AUX):
+                # off the critical path, like the dense weight gradients: the (memory-bound) reduction runs on the
+                # auxiliary stream beside the MFMA kernels of the next backward nodes and lands in the arena
+                aux = streams.fork(dy.device)
+                with torch.cuda.stream(aux):
+                    B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo,
+                                                        stride[0], padding[0], padding[1], dilation[0],
+                                                        B.stream_ptr()), "dwconv_bwd_weight")
+                    sink.view(c, 9).add_(dw9.t())
+                dy.record_stream(aux)
+                x.record_stream(aux)
+                notify = getattr(wp, "_dpamd_on_grad", None)
+                if notify is not None:
+                    notify(wp)
+            else:
+                B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo, stride[0],
+                                                    padding[0], padding[1], dilation[0], B.stream_ptr()),
+                        "dwconv_bwd_weight")
+                dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
         return dx, dw, None, None, None, None, None
 
 

@@ -36,6 +36,10 @@ from . import _backend as B
 from .conv import conv_bn_act
 
 _FOLD = os.environ.get("DPAMD_SEPCONV_FOLD", "1") != "0"
+# backward schedule of the folded unit: "1" = weight gradient -> data gradient with the statistics term in its
+# store loop (one pass less over the activation), "0" = weight and data gradient side by side on two streams and
+# a separate elementwise pass for the statistics term
+_SERIAL = os.environ.get("DPAMD_SEPCONV_SERIAL", "1") != "0"
 
 
 def _sink_of(p):
@@ -77,21 +81,25 @@ class _FoldedPointwise(torch.autograd.Function):
         cout, cin = wf.shape[:2]
         n, _, h, w = z.shape
         dy = _hip_bn.as_nhwc(dy)
-        # weight gradient w.r.t. the folded weights: beside the data gradient, on the auxiliary stream
+        # 1. weight gradient w.r.t. the folded weights (needed first: ds, hence the data gradient's statistics
+        #    term, comes out of it)
         dwf = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=z.device,
                           memory_format=torch.channels_last).zero_()
+        serial = _SERIAL or not streams.enabled()
         aux = None
-        if streams.enabled():
+        if serial:
+            _hip_conv.wgrad(dy, z, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=dwf)
+        else:
             aux = streams.fork(z.device)
             with torch.cuda.stream(aux):
                 _hip_conv.wgrad(dy, z, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=dwf)
             dy.record_stream(aux)
             z.record_stream(aux)
             dwf.record_stream(aux)
-        else:
-            _hip_conv.wgrad(dy, z, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=dwf)
+        need_dz = ctx.needs_input_grad[0]
         dz = None
-        if ctx.needs_input_grad[0]:
+        if need_dz and not serial:
+            # data gradient beside the weight gradient; the statistics term is a separate pass behind both
             dz = _hip_conv.igemm(dy, _hip_conv.weight_transpose(wf), (h, w), 1, 1, (0, 0), (1, 1))
         if aux is not None:
             torch.cuda.current_stream(z.device).wait_stream(aux)
@@ -104,7 +112,11 @@ class _FoldedPointwise(torch.autograd.Function):
             dgamma = torch.zeros(cin, dtype=torch.float32, device=z.device)
         cc = _hip_bn.fold_backward(dwf, w_lowp, vec, g32, w_sink if w_sink is not None else dw,
                                    g_sink if g_sink is not None else dgamma, ctx.count)
-        if dz is not None:
+        if need_dz and serial:
+            # 2. dz = W'^T dy + c * z - c * mean in ONE kernel: the statistics term rides in the store loop
+            dz = _hip_conv.igemm(dy, _hip_conv.weight_transpose(wf), (h, w), 1, 1, (0, 0), (1, 1),
+                                 residual=z, residual_affine=cc)
+        elif need_dz:
             _hip_bn.affine_add_(dz, z, cc[0], cc[1])
         if ctx.needs_input_grad[2] and _sink_of(beta) is None:
             dbeta = torch.zeros(cin, dtype=beta.dtype, device=z.device)
