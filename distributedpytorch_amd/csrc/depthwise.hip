@@ -548,8 +548,14 @@ struct Dw4 {
     int N, C, H, W, dil, TS, NR, hsplit, rows_split, flip, rowpx;
     unsigned in_bytes;
     float* stats; int stat_reps;
+    // MODE 1 (data gradient with the previous layer's BatchNorm+ReLU backward prologue, as in the dense kernels'
+    // store loop): out = (conv + res) * [bna > 0]; stats <- per-channel sums of out and out * xhat,
+    // xhat = (bnx - mean) * rstd.  res may be null; bna null = plain "conv + res" (no mask, no sums).
+    const bf16_raw* res; const bf16_raw* bna; const bf16_raw* bnx; const float* bn_mean; const float* bn_rstd;
 };
 
+//   MODE 0: out = depthwise conv of `in` (+ BatchNorm statistics of out);  MODE 1: see Dw4::res;
+//   MODE 2: dw[t][c] += sum of in2 (dy) x tap t of `in` (x)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
@@ -597,11 +603,19 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     };
 
     // MODE 0: tap weights as packed pairs — wp[tp][c] = (w[2 tp][c], w[2 tp + 1][c]); the ninth tap pairs with zero
-    unsigned wp[MODE == 0 ? 4 : 1][8], w8[MODE == 0 ? 8 : 1];
+    unsigned wp[MODE <= 1 ? 4 : 1][8], w8[MODE <= 1 ? 8 : 1];
+    float mu[MODE == 1 ? 8 : 1], is[MODE == 1 ? 8 : 1];
     float acc2[MODE == 2 ? 9 : 1][8];
     float s1[8], s2[8];
     uint4 dq[kDw4K], dqn[kDw4K];
-    if (MODE == 0) {
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = (cg_ok && p.bna) ? p.bn_mean[c0 + cg * 8 + j] : 0.f;
+            is[j] = (cg_ok && p.bna) ? p.bn_rstd[c0 + cg * 8 + j] : 0.f;
+        }
+    }
+    if (MODE <= 1) {
         uint4 wr[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -626,7 +640,8 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
         load_dy(dq, ya);
     }
     stage(ya - d, TS + 2 * d);
-    bf16_raw* outp = MODE == 0 ? reinterpret_cast<bf16_raw*>(p.out) + ((long)n * p.H * W) * p.C + c0 + cg * 8 : nullptr;
+    const long img_el = ((long)n * p.H * W) * p.C + c0 + cg * 8;
+    bf16_raw* outp = MODE <= 1 ? reinterpret_cast<bf16_raw*>(p.out) + img_el : nullptr;
 
     for (int y0 = ya; y0 < yb; y0 += TS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -639,11 +654,17 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
         const int npix = min(TS, yb - y0) * W;
         const int rbase = (y0 - ya) % NR;
         int ry = pl / W, x = pl - ry * W;
-        if (MODE == 0) {
+        if (MODE <= 1) {
 #pragma unroll
             for (int k = 0; k < kDw4K; ++k) {
                 const int pi = pl + 32 * k;
                 if (pi < npix) {
+                    uint4 ga = make_uint4(0, 0, 0, 0), gx = ga, gr = ga;      // MODE 1: issued ahead of the tap reads
+                    if (MODE == 1 && cg_ok) {
+                        const long go = img_el + ((long)y0 * W + pi) * p.C;
+                        if (p.bna) { ga = *reinterpret_cast<const uint4*>(p.bna + go); gx = *reinterpret_cast<const uint4*>(p.bnx + go); }
+                        if (p.res) gr = *reinterpret_cast<const uint4*>(p.res + go);
+                    }
                     int r0 = rbase + ry;  r0 -= r0 >= NR ? NR : 0;
                     int r1 = r0 + d;      r1 -= r1 >= NR ? NR : 0;
                     int r2 = r1 + d;      r2 -= r2 >= NR ? NR : 0;
@@ -669,9 +690,30 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                         acc[2 * i] = dot2bf(wsel(v[8], i), w8[2 * i], acc[2 * i]);
                         acc[2 * i + 1] = dot2bf(wsel(v[8], i), w8[2 * i + 1], acc[2 * i + 1]);
                     }
-                    if (cg_ok) *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = pack8(acc);
+                    if (MODE == 1) {
+                        float rv[8];
+                        unpack8(gr, rv);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
+                        for (int j = 0; j < 8; ++j) acc[j] += rv[j];
+                        if (p.bna) {                     // uniform
+                            float av[8], xv[8];
+                            unpack8(ga, av);
+                            unpack8(gx, xv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] = av[j] > 0.f ? acc[j] : 0.f;
+                            const uint4 o = pack8(acc);
+                            unpack8(o, acc);             // reduce exactly what BN backward will read back
+                            if (cg_ok) *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], (xv[j] - mu[j]) * is[j], s2[j]); }
+                        } else if (cg_ok) {
+                            *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = pack8(acc);
+                        }
+                    } else {
+                        if (cg_ok) *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = pack8(acc);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
+                    }
                 }
                 x += 32;
                 while (x >= W) { x -= W; ++ry; }
@@ -740,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
         }
     }
     __syncthreads();                                     // everyone is done with the ring
-    if (MODE == 0) {
+    if (MODE <= 1) {
         if (p.stats) {                                   // uniform
             float* red = reinterpret_cast<float*>(smem4);       // [32 pixel lanes][8 cg][16]
 #pragma unroll
@@ -779,9 +821,11 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     }
 }
 
+struct Dw4Bn { const void* res; const void* bna; const void* bnx; const float* mean; const float* rstd; };
+
 template <int MODE>
 inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
-                      int flip, hipStream_t st, float* stats = nullptr, int stat_reps = 1) {
+                      int flip, hipStream_t st, float* stats = nullptr, int stat_reps = 1, Dw4Bn bn = Dw4Bn{}) {
     const long in_bytes = (long)N * H * W * C * 2;
     if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
     const int rowpx = (W + 2 * dil + 7) / 8 * 8;
@@ -801,7 +845,7 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
     long lds = NR * row_bytes;
     const int bpc = lds * 2 <= 160 * 1024 ? 2 : 1;
     if (MODE == 2 && lds < 32 * 8 * 72 * 4) lds = 32 * 8 * 72 * 4;
-    if (MODE == 0 && stats && lds < 32 * 8 * 16 * 4) lds = 32 * 8 * 16 * 4;
+    if (MODE <= 1 && stats && lds < 32 * 8 * 16 * 4) lds = 32 * 8 * 16 * 4;
     if (lds > 160 * 1024) return -2;
     // horizontal bands: the grid should fill whole rounds of the 256 x bpc resident block slots; a band costs its
     // rows plus the 2d halo rows it re-reads
@@ -821,7 +865,8 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
     const long nb = (long)N * hsplit;
     if (nb > 0x7fffffffL) return -4;
     Dw4 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TS, NR, hsplit, rows_split,
-          flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps};
+          flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps,
+          (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd};
     auto kfn = dwconv4_kernel<MODE>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
@@ -944,4 +989,21 @@ DP_EXPORT int dp_dwconv_fwd_stats(const void* x, const void* w9, void* y, float*
     const int th = dw3_rows(Hi, Wi, dil, false);
     if (th <= 0) return -2;
     return launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st, stats, stat_reps);
+}
+
+// Data gradient (stride 1, "same" padding) with the skip-path gradient `res` (or null) added and, when bna / bnx are
+// given, the previous layer's BatchNorm+ReLU backward prologue: dx = (convT(dy) + res) * [bna > 0] and
+// sums fp32 [reps][2][C] (zero-initialised) += per-channel (sum dx, sum dx * (bnx - mean) * rstd).
+// Returns -2 when the rolling-window kernel does not take the shape (nothing was launched).
+DP_EXPORT int dp_dwconv_bwd_data_fused(const void* dy, const void* w9, void* dx, const void* res, const void* bna,
+                                       const void* bnx, const float* bn_mean, const float* bn_rstd, float* sums,
+                                       int reps, int N, int C, int H, int W, int dil, hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || dil < 1 || H <= 0 || W <= 0) return -1;
+    if ((bna != nullptr) != (bnx != nullptr)) return -1;
+    if (bna && (!bn_mean || !bn_rstd || !sums || reps < 1)) return -1;
+    if (!bna && !res) return -1;
+    if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)res | (uintptr_t)bna | (uintptr_t)bnx | (uintptr_t)w9) & 15) return -3;
+    if (kDwGen < 4) return -2;
+    return launch_dw4<1>(dy, nullptr, w9, dx, N, C, H, W, dil, 1, st, bna ? sums : nullptr, reps,
+                         Dw4Bn{res, bna, bnx, bn_mean, bn_rstd});
 }

@@ -44,10 +44,10 @@ class _Unit(nn.Module):
         self.bn = BatchNorm2d(cout)
         self.relu_after = relu_after
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, passthrough=False, sole_consumer=False):
         # (GPU training path: the depthwise BatchNorm is folded into the pointwise weights, ops.sepconv)
         return sepconv_bn_act(self.sep, self.bn, x, relu=self.relu_after if relu is None else relu,
-                              residual=residual)
+                              residual=residual, passthrough=passthrough, sole_consumer=sole_consumer)
 
 
 class XceptionBlock(nn.Module):
@@ -61,6 +61,8 @@ class XceptionBlock(nn.Module):
         self.activate_output = False
         # ... and the block that receives such an input does not activate it again
         self.input_activated = False
+        # set by AlignedXception: nothing but this block consumes its input tensor
+        self.input_sole = False
         if cout != cin or stride != 1:
             self.skip = Conv2d(cin, cout, 1, stride=stride, bias=False)
             self.skipbn = BatchNorm2d(cout)
@@ -86,14 +88,28 @@ class XceptionBlock(nn.Module):
 
     def forward(self, inp):
         x = torch.relu(inp) if (self.start_with_relu and not self.input_activated) else inp
+        # `x` is a fused BN+ReLU output consumed by nothing but this block: its BatchNorm's backward reductions
+        # ride in the first backward kernel that sees the block's whole input gradient (ops.sepconv / ops.conv)
+        sole = self.input_sole and x is inp
+        units = list(self.rep)
         # pre-activation quirk of the published weights: the shortcut sees the activated input
-        short = x
         if self.skip is not None:
-            x = self.rep(x)
+            if self.skipbn.training and not self.skipbn.frozen and self.skip.can_fuse_stats(x) \
+                    and self.skip.can_passthrough(x):
+                # the shortcut convolution first, the units on its passthrough: the units' input gradient is added in
+                # the shortcut's data-gradient store loop (no add kernel)
+                sk, st, x = self.skip(x, with_stats=True, passthrough=True, sole_consumer=sole)
+                for i, unit in enumerate(units):
+                    x = unit(x, sole_consumer=i > 0)
+                return self.skipbn(sk, relu=self.activate_output, residual=x, stats=st)
+            short = x
+            for i, unit in enumerate(units):
+                x = unit(x, sole_consumer=i > 0)
             return conv_bn_act(self.skip, self.skipbn, short, residual=x, relu=self.activate_output)
-        for unit in list(self.rep)[:-1]:
-            x = unit(x)
-        return self.rep[-1](x, residual=short, relu=self.activate_output)
+        x, short = units[0](x, passthrough=True, sole_consumer=sole)
+        for unit in units[1:-1]:
+            x = unit(x, sole_consumer=True)
+        return units[-1](x, residual=short, relu=self.activate_output, sole_consumer=True)
 
 
 class AlignedXception(nn.Module):
@@ -131,6 +147,10 @@ class AlignedXception(nn.Module):
             blk.activate_output = True
         for blk in chain[1:]:
             blk.input_activated = True
+        # block1's input (conv2 + BN + ReLU) and every block output except block1's (`low` also feeds the decoder)
+        # have exactly one consumer
+        for blk in chain:
+            blk.input_sole = blk is not self.block2
 
     def forward(self, x):
         x = conv_bn_act(self.conv1, self.bn1, x, relu=True)
@@ -140,7 +160,7 @@ class AlignedXception(nn.Module):
         x = self.block3(x)
         x = self.middle(x)
         x = self.block20(x)
-        x = sepconv_bn_act(self.conv3, self.bn3, x, relu=True)
-        x = sepconv_bn_act(self.conv4, self.bn4, x, relu=True)
-        x = sepconv_bn_act(self.conv5, self.bn5, x, relu=True)
+        x = sepconv_bn_act(self.conv3, self.bn3, x, relu=True, sole_consumer=True)
+        x = sepconv_bn_act(self.conv4, self.bn4, x, relu=True, sole_consumer=True)
+        x = sepconv_bn_act(self.conv5, self.bn5, x, relu=True, sole_consumer=True)
         return x, low

@@ -39,6 +39,7 @@ def _lib():
         lib.dp_conv_igemm2w.argtypes = [V, V, V, V, V] + [I] * 19 + [V]
         lib.dp_conv_wgrad_win.argtypes = [V, V, V] + [I] * 12 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
+        lib.dp_dwconv_bwd_data_fused.argtypes = [V] * 9 + [I] * 6 + [V]
         lib.dp_dwconv_fwd_stats.argtypes = [V, V, V, V] + [I] * 11 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 10 + [V]
@@ -616,7 +617,12 @@ class _StemConv(torch.autograd.Function):
 
 class _DepthwiseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, w_lowp, stride, padding, dilation, with_stats=False):
+    def forward(ctx, x, weight, w_lowp, stride, padding, dilation, with_stats=False, passthrough=False,
+                bn_holder=None):
+        """``passthrough``: additionally return ``x`` itself as the LAST output (a block routes its shortcut
+        through it: the skip-path gradient is then added inside the data-gradient kernel).  ``bn_holder``: ``x`` is
+        relu(BN(..)) of a layer whose whole gradient leaves this node — that layer's backward prologue (mask,
+        reductions) runs in the data-gradient kernel's epilogue (csrc/depthwise.hip, MODE 1)."""
         c = x.shape[1]
         n, _, hi, wi = x.shape
         if weight.shape[2:] != (3, 3) or c % 8:
@@ -644,19 +650,25 @@ class _DepthwiseConv(torch.autograd.Function):
         ctx.save_for_backward(x, w9)
         ctx.geom = (stride, padding, dilation, (hi, wi), (ho, wo))
         ctx.weight_param = weight
+        ctx.passthrough = passthrough
+        ctx.bn_holder = bn_holder if (bn_holder and "x" in bn_holder) else None
+        outs = [y]
         if with_stats:
             if stats is None:
                 from . import _hip_bn
                 s1, s2 = _hip_bn.stats(y)
                 stats = torch.stack([s1, s2]).unsqueeze(0)
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y
+            outs.append(stats)
+        if passthrough:
+            outs.append(x.view_as(x))
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, dy, *unused):
+    def backward(ctx, dy, *rest):
+        dskip = rest[-1] if ctx.passthrough else None
         if dy is None:
-            return (None,) * 7
+            return (dskip,) + (None,) * 8
         x, w9 = ctx.saved_tensors
         stride, padding, dilation, (hi, wi), (ho, wo) = ctx.geom
         n, c = x.shape[:2]
@@ -664,8 +676,42 @@ class _DepthwiseConv(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            B.check(_lib().dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), n, c, hi, wi, ho, wo, stride[0],
-                                              padding[0], padding[1], dilation[0], B.stream_ptr()), "dwconv_bwd_data")
+            if dskip is not None:
+                dskip = as_nhwc(dskip)
+            h = ctx.bn_holder
+            fused = False
+            if (h is not None or dskip is not None) and stride[0] == 1 and padding[0] == dilation[0] \
+                    and padding[1] == dilation[0] and (ho, wo) == (hi, wi):
+                bx = h["x"] if h is not None else None
+                if bx is not None and (tuple(bx.shape) != tuple(x.shape) or bx.dtype != torch.bfloat16
+                                       or not bx.is_contiguous(memory_format=torch.channels_last)):
+                    h = bx = None
+                if dskip is not None and (dskip.shape != x.shape or dskip.dtype != torch.bfloat16):
+                    raise ValueError("depthwise passthrough: skip gradient does not match the input")
+                if bx is not None or dskip is not None:
+                    sums, reps = None, 1
+                    if bx is not None:
+                        reps = stat_replicas(n * hi * wi)
+                        sums = workspace.zeros(reps * 2 * c, x.device).view(reps, 2, c)
+                    st = _lib().dp_dwconv_bwd_data_fused(
+                        B.ptr(dy), B.ptr(w9), B.ptr(dx), B.ptr(dskip), B.ptr(x if bx is not None else None),
+                        B.ptr(bx), B.ptr(h["mean"] if bx is not None else None),
+                        B.ptr(h["invstd"] if bx is not None else None), B.ptr(sums), reps, n, c, hi, wi, dilation[0],
+                        B.stream_ptr())
+                    if st != -2:
+                        B.check(st, "dwconv_bwd_data_fused")
+                        fused = True
+                        if bx is not None:
+                            h["sums"] = sums
+                            h["dm_ptr"] = dx.data_ptr()
+            if not fused:
+                B.check(_lib().dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), n, c, hi, wi, ho, wo, stride[0],
+                                                  padding[0], padding[1], dilation[0], B.stream_ptr()),
+                        "dwconv_bwd_data")
+                if dskip is not None:
+                    dx += dskip
+        elif dskip is not None:
+            dx = dskip
         if ctx.needs_input_grad[1]:
             dw9 = workspace.zeros(9 * c, x.device).view(9, c)
             wp = ctx.weight_param
@@ -690,7 +736,7 @@ class _DepthwiseConv(torch.autograd.Function):
                                                     padding[0], padding[1], dilation[0], B.stream_ptr()),
                         "dwconv_bwd_weight")
                 dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stats=False, passthrough=False,
@@ -705,14 +751,15 @@ def conv2d(x, weight, bias, stride, padding, dilation, groups, w_lowp, with_stat
         holder = getattr(x, "_dpamd_bn_holder", None) if (sole_consumer and _BN_PROLOGUE) else None
         return _ConvIGemm.apply(x, weight, bias, w_lowp, stride, padding, dilation, with_stats, passthrough,
                                 holder)
-    if passthrough:
-        raise NotImplementedError("passthrough is a dense-convolution feature")
     if groups == x.shape[1] == weight.shape[0] and weight.shape[1] == 1:
         if bias is not None:
             raise NotImplementedError("depthwise bias")
         if dilation[0] != dilation[1] or stride[0] != stride[1]:
             raise NotImplementedError("anisotropic depthwise")
-        return _DepthwiseConv.apply(x, weight, w_lowp, stride, padding, dilation, with_stats)
+        holder = getattr(x, "_dpamd_bn_holder", None) if (sole_consumer and _BN_PROLOGUE) else None
+        return _DepthwiseConv.apply(x, weight, w_lowp, stride, padding, dilation, with_stats, passthrough, holder)
+    if passthrough:
+        raise NotImplementedError("passthrough: dense and depthwise convolutions only")
     if with_stats:
         raise NotImplementedError("fused statistics: dense and depthwise convolutions only")
     raise NotImplementedError(f"grouped convolution with groups={groups} (only dense and depthwise)")

@@ -117,8 +117,10 @@ class Conv2d(nn.Module):
                       self.groups, w_lowp, with_stats, passthrough, sole_consumer)
 
     def can_passthrough(self, x: torch.Tensor) -> bool:
-        return (B.use_hip(x) and self.groups == 1 and self.in_channels % 8 == 0 and x.dtype == torch.bfloat16
-                and torch.is_grad_enabled() and x.requires_grad)
+        depthwise = (self.groups == self.in_channels == self.out_channels and self.kernel_size == (3, 3)
+                     and self.bias is None)
+        return (B.use_hip(x) and (self.groups == 1 or depthwise) and self.in_channels % 8 == 0
+                and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad)
 
     def can_fuse_stats(self, x: torch.Tensor) -> bool:
         dense = self.groups == 1

@@ -143,13 +143,34 @@ def can_fold(sep, bn2, x: torch.Tensor) -> bool:
 
 
 def sepconv_bn_act(sep, bn2, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                   dropout: float = 0.0):
+                   dropout: float = 0.0, passthrough: bool = False, sole_consumer: bool = False):
     """``act(BN2(pointwise(BN1(depthwise(x)))) + residual)`` for a ``models.xception.SeparableConv2d`` ``sep``.
     Training on the GPU path with local (non-synchronised, non-frozen) statistics folds BN1 into the pointwise
-    weights; everything else runs the ordinary composition."""
+    weights; everything else runs the ordinary composition.
+
+    ``passthrough=True`` returns ``(out, x')``: ``x'`` is ``x`` routed through the depthwise node — use it as the
+    block's shortcut and its gradient is added inside the depthwise data-gradient kernel (no add kernel).
+    ``sole_consumer``: ``x`` (a fused BN+ReLU output) feeds nothing but this unit (and its passthrough), so that
+    BatchNorm's backward reductions run in the same kernel's epilogue."""
+    dw = sep.conv1
+    pt = passthrough and dw.can_passthrough(x)
     if not can_fold(sep, bn2, x):
-        return conv_bn_act(sep.pointwise, bn2, sep.depthwise_bn(x), relu=relu, residual=residual, dropout=dropout)
-    z, stats1 = sep.conv1(x, with_stats=True)
+        if bn2.training and not sep.bn.frozen and dw.can_fuse_stats(x) and (pt or sole_consumer) and sep.bn.training:
+            if pt:
+                z, st, skip = dw(x, with_stats=True, passthrough=True, sole_consumer=sole_consumer)
+            else:
+                z, st = dw(x, with_stats=True, sole_consumer=sole_consumer)
+            a = sep.bn(z, stats=st)
+        else:
+            pt = False
+            a = sep.depthwise_bn(x)
+        out = conv_bn_act(sep.pointwise, bn2, a, relu=relu, residual=residual, dropout=dropout)
+        return (out, skip if pt else x) if passthrough else out
+    if pt:
+        z, stats1, skip = dw(x, with_stats=True, passthrough=True, sole_consumer=sole_consumer)
+    else:
+        z, stats1 = dw(x, with_stats=True, sole_consumer=sole_consumer)
     bn1, pw = sep.bn, sep.pointwise
     y, stats2 = _FoldedPointwise.apply(z, bn1.weight, bn1.bias, pw.weight, stats1, pw.lowp_weight(x.dtype), bn1, bn2)
-    return bn2(y, relu=relu, residual=residual, stats=stats2, dropout=dropout)
+    out = bn2(y, relu=relu, residual=residual, stats=stats2, dropout=dropout)
+    return (out, skip if pt else x) if passthrough else out
