@@ -551,7 +551,10 @@ struct Dw4 {
     // MODE 1 (data gradient with the previous layer's BatchNorm+ReLU backward prologue, as in the dense kernels'
     // store loop): out = (conv + res) * [bna > 0]; stats <- per-channel sums of out and out * xhat,
     // xhat = (bnx - mean) * rstd.  res may be null; bna null = plain "conv + res" (no mask, no sums).
+    // bna null with bnx given: the mask is recomputed, bnx * (w * rstd) + (b - mean * w * rstd) > 0 (no residual
+    // entered that activation); bn_w / bn_b null = 1 / 0.
     const bf16_raw* res; const bf16_raw* bna; const bf16_raw* bnx; const float* bn_mean; const float* bn_rstd;
+    const float* bn_w; const float* bn_b;
 };
 
 //   MODE 0: out = depthwise conv of `in` (+ BatchNorm statistics of out);  MODE 1: see Dw4::res;
@@ -604,16 +607,31 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
 
     // MODE 0: tap weights as packed pairs — wp[tp][c] = (w[2 tp][c], w[2 tp + 1][c]); the ninth tap pairs with zero
     unsigned wp[MODE <= 1 ? 4 : 1][8], w8[MODE <= 1 ? 8 : 1];
-    float mu[MODE == 1 ? 8 : 1], is[MODE == 1 ? 8 : 1];
+    float mu[MODE == 1 ? 8 : 1], is[MODE == 1 ? 8 : 1], msc[MODE == 1 ? 8 : 1], msh[MODE == 1 ? 8 : 1];
+    uint4 bx[MODE == 1 ? kDw4K : 1], bxn[MODE == 1 ? kDw4K : 1];     // bnx of this / the next step's pixels
     float acc2[MODE == 2 ? 9 : 1][8];
     float s1[8], s2[8];
     uint4 dq[kDw4K], dqn[kDw4K];
+    auto load_bx = [&](uint4 (&q)[MODE == 1 ? kDw4K : 1], int y0) {
+        const int npix = min(TS, yb - y0) * W;
+#pragma unroll
+        for (int k = 0; k < (MODE == 1 ? kDw4K : 1); ++k) {
+            const int pi = pl + 32 * k;
+            q[k] = make_uint4(0, 0, 0, 0);
+            if (cg_ok && pi < npix)
+                q[k] = *reinterpret_cast<const uint4*>(p.bnx + ((long)n * p.H * W + (long)y0 * W + pi) * p.C + c0 + cg * 8);
+        }
+    };
     if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            mu[j] = (cg_ok && p.bna) ? p.bn_mean[c0 + cg * 8 + j] : 0.f;
-            is[j] = (cg_ok && p.bna) ? p.bn_rstd[c0 + cg * 8 + j] : 0.f;
+            const bool on = cg_ok && p.bnx;
+            mu[j] = on ? p.bn_mean[c0 + cg * 8 + j] : 0.f;
+            is[j] = on ? p.bn_rstd[c0 + cg * 8 + j] : 0.f;
+            msc[j] = (on && p.bn_w ? p.bn_w[c0 + cg * 8 + j] : 1.f) * is[j];
+            msh[j] = fmaf(-mu[j], msc[j], on && p.bn_b ? p.bn_b[c0 + cg * 8 + j] : 0.f);
         }
+        if (p.bnx) load_bx(bx, ya);
     }
     if (MODE <= 1) {
         uint4 wr[9];
@@ -650,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
         if (more) {
             stage(y0 + TS + d, TS);
             if (MODE == 2) load_dy(dqn, y0 + TS);
+            if (MODE == 1 && p.bnx) load_bx(bxn, y0 + TS);
         }
         const int npix = min(TS, yb - y0) * W;
         const int rbase = (y0 - ya) % NR;
@@ -659,10 +678,10 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
             for (int k = 0; k < kDw4K; ++k) {
                 const int pi = pl + 32 * k;
                 if (pi < npix) {
-                    uint4 ga = make_uint4(0, 0, 0, 0), gx = ga, gr = ga;      // MODE 1: issued ahead of the tap reads
+                    uint4 ga = make_uint4(0, 0, 0, 0), gr = ga;      // MODE 1: issued ahead of the tap reads
                     if (MODE == 1 && cg_ok) {
                         const long go = img_el + ((long)y0 * W + pi) * p.C;
-                        if (p.bna) { ga = *reinterpret_cast<const uint4*>(p.bna + go); gx = *reinterpret_cast<const uint4*>(p.bnx + go); }
+                        if (p.bna) ga = *reinterpret_cast<const uint4*>(p.bna + go);
                         if (p.res) gr = *reinterpret_cast<const uint4*>(p.res + go);
                     }
                     int r0 = rbase + ry;  r0 -= r0 >= NR ? NR : 0;
@@ -695,10 +714,15 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                         unpack8(gr, rv);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) acc[j] += rv[j];
-                        if (p.bna) {                     // uniform
+                        if (p.bnx) {                     // uniform
                             float av[8], xv[8];
-                            unpack8(ga, av);
-                            unpack8(gx, xv);
+                            unpack8(bx[k], xv);
+                            if (p.bna) {                 // uniform
+                                unpack8(ga, av);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) av[j] = fmaf(xv[j], msc[j], msh[j]);
+                            }
 #pragma unroll
                             for (int j = 0; j < 8; ++j) acc[j] = av[j] > 0.f ? acc[j] : 0.f;
                             const uint4 o = pack8(acc);
@@ -776,6 +800,10 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                 }
             }
         }
+        if (MODE == 1 && p.bnx) {
+#pragma unroll
+            for (int k = 0; k < (MODE == 1 ? kDw4K : 1); ++k) bx[k] = bxn[k];
+        }
         if (MODE == 2) {
 #pragma unroll
             for (int k = 0; k < kDw4K; ++k) dq[k] = dqn[k];
@@ -821,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     }
 }
 
-struct Dw4Bn { const void* res; const void* bna; const void* bnx; const float* mean; const float* rstd; };
+struct Dw4Bn { const void* res; const void* bna; const void* bnx; const float* mean; const float* rstd; const float* w; const float* b; };
 
 template <int MODE>
 inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
@@ -866,7 +894,7 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
     if (nb > 0x7fffffffL) return -4;
     Dw4 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TS, NR, hsplit, rows_split,
           flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps,
-          (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd};
+          (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd, bn.w, bn.b};
     auto kfn = dwconv4_kernel<MODE>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
@@ -991,19 +1019,21 @@ DP_EXPORT int dp_dwconv_fwd_stats(const void* x, const void* w9, void* y, float*
     return launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st, stats, stat_reps);
 }
 
-// Data gradient (stride 1, "same" padding) with the skip-path gradient `res` (or null) added and, when bna / bnx are
-// given, the previous layer's BatchNorm+ReLU backward prologue: dx = (convT(dy) + res) * [bna > 0] and
-// sums fp32 [reps][2][C] (zero-initialised) += per-channel (sum dx, sum dx * (bnx - mean) * rstd).
+// Data gradient (stride 1, "same" padding) with the skip-path gradient `res` (or null) added and, when bnx is given,
+// the previous layer's BatchNorm+ReLU backward prologue: dx = (convT(dy) + res) * mask and sums fp32 [reps][2][C]
+// (zero-initialised) += per-channel (sum dx, sum dx * (bnx - mean) * rstd).  mask = [bna > 0] when bna (the
+// activation itself) is given, else [bnx * w * rstd + b - mean * w * rstd > 0] (bn_w / bn_b may be null: 1 / 0).
 // Returns -2 when the rolling-window kernel does not take the shape (nothing was launched).
 DP_EXPORT int dp_dwconv_bwd_data_fused(const void* dy, const void* w9, void* dx, const void* res, const void* bna,
-                                       const void* bnx, const float* bn_mean, const float* bn_rstd, float* sums,
-                                       int reps, int N, int C, int H, int W, int dil, hipStream_t st) {
+                                       const void* bnx, const float* bn_mean, const float* bn_rstd, const float* bn_w,
+                                       const float* bn_b, float* sums, int reps, int N, int C, int H, int W, int dil,
+                                       hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || dil < 1 || H <= 0 || W <= 0) return -1;
-    if ((bna != nullptr) != (bnx != nullptr)) return -1;
-    if (bna && (!bn_mean || !bn_rstd || !sums || reps < 1)) return -1;
-    if (!bna && !res) return -1;
+    if (bna && !bnx) return -1;
+    if (bnx && (!bn_mean || !bn_rstd || !sums || reps < 1)) return -1;
+    if (!bnx && !res) return -1;
     if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)res | (uintptr_t)bna | (uintptr_t)bnx | (uintptr_t)w9) & 15) return -3;
     if (kDwGen < 4) return -2;
-    return launch_dw4<1>(dy, nullptr, w9, dx, N, C, H, W, dil, 1, st, bna ? sums : nullptr, reps,
-                         Dw4Bn{res, bna, bnx, bn_mean, bn_rstd});
+    return launch_dw4<1>(dy, nullptr, w9, dx, N, C, H, W, dil, 1, st, bnx ? sums : nullptr, reps,
+                         Dw4Bn{res, bna, bnx, bn_mean, bn_rstd, bn_w, bn_b});
 }

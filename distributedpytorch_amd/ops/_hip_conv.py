@@ -39,7 +39,7 @@ def _lib():
         lib.dp_conv_igemm2w.argtypes = [V, V, V, V, V] + [I] * 19 + [V]
         lib.dp_conv_wgrad_win.argtypes = [V, V, V] + [I] * 12 + [V]
         lib.dp_dwconv_fwd.argtypes = [V, V, V] + [I] * 10 + [V]
-        lib.dp_dwconv_bwd_data_fused.argtypes = [V] * 9 + [I] * 6 + [V]
+        lib.dp_dwconv_bwd_data_fused.argtypes = [V] * 11 + [I] * 6 + [V]
         lib.dp_dwconv_fwd_stats.argtypes = [V, V, V, V] + [I] * 11 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 10 + [V]
@@ -693,11 +693,14 @@ class _DepthwiseConv(torch.autograd.Function):
                     if bx is not None:
                         reps = stat_replicas(n * hi * wi)
                         sums = workspace.zeros(reps * 2 * c, x.device).view(reps, 2, c)
+                    # mask source: the activation itself (= this node's input) where a residual entered it, else
+                    # recomputed from the BatchNorm input the kernel reads anyway (one tensor less to fetch)
+                    ba = x if (bx is not None and h.get("mask_from_a")) else None
+                    hv = (lambda k: h.get(k) if bx is not None else None)
                     st = _lib().dp_dwconv_bwd_data_fused(
-                        B.ptr(dy), B.ptr(w9), B.ptr(dx), B.ptr(dskip), B.ptr(x if bx is not None else None),
-                        B.ptr(bx), B.ptr(h["mean"] if bx is not None else None),
-                        B.ptr(h["invstd"] if bx is not None else None), B.ptr(sums), reps, n, c, hi, wi, dilation[0],
-                        B.stream_ptr())
+                        B.ptr(dy), B.ptr(w9), B.ptr(dx), B.ptr(dskip), B.ptr(ba), B.ptr(bx), B.ptr(hv("mean")),
+                        B.ptr(hv("invstd")), B.ptr(hv("w")), B.ptr(hv("b")), B.ptr(sums), reps, n, c, hi, wi,
+                        dilation[0], B.stream_ptr())
                     if st != -2:
                         B.check(st, "dwconv_bwd_data_fused")
                         fused = True
