@@ -692,6 +692,9 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
         case 16: return launch2<192, 128, 2, 2, 2, 3, 32>(p, unit, st);
         case 17: return launch2<256, 128, 4, 2, 2, 4, 32>(p, unit, st);
         case 18: return launch2<128, 256, 2, 4, 2, 4, 32>(p, unit, st);
+        // (256x256 on FOUR waves — wave tile 128x128, accumulators in AGPRs, a third less fragment traffic — was
+        // measured 2.4x SLOWER than case 5 on the K = 728 pointwise layers: 1150 vs 471 us, gpurun_out/n/shapes.log;
+        // one wave per SIMD hides neither the LDS round trips nor the spills of its 512-register budget)
         default: return -2;
     }
 }

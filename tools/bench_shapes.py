@@ -25,6 +25,7 @@ def timeit(fn, iters=7, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--cfgs", default="", help="comma-separated tile configurations to time the forward with (else autotuned)")
     ap.add_argument("shapes", nargs="+", help="cin:cout:hw:k[:dil]")
     a = ap.parse_args()
     print(f"{'shape':22s} {'GF':>8s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}")
@@ -40,6 +41,9 @@ def main():
         wt = _hip_conv.weight_transpose(w)
         dw = torch.zeros(cout, cin, k, k, device="cuda").contiguous(memory_format=torch.channels_last)
         gf = 2.0 * a.batch * hw * hw * cin * cout * k * k / 1e9
+        for c in [int(v) for v in a.cfgs.split(",") if v]:
+            t_c = timeit(lambda: _hip_conv.igemm(x, w, (hw, hw), 1, 1, (pad, pad), (dil, dil), cfg=c))
+            print(f"    cfg {c:2d}: {t_c:8.1f} us {gf / t_c * 1e3:6.0f} TF", flush=True)
         t_f = timeit(lambda: _hip_conv.igemm(x, w, (hw, hw), 1, 1, (pad, pad), (dil, dil)))
         t_d = timeit(lambda: _hip_conv.igemm(dy, wt, (hw, hw), 1, 1, (pad, pad), (dil, dil)))
         t_w = timeit(lambda: _hip_conv.wgrad(dy, x, (cout, cin, k, k), (1, 1), (pad, pad), (dil, dil), out=dw))

@@ -8,12 +8,14 @@ import re
 import sys
 
 FAMILIES = [
+    # (own kernels first: `dwconv_bwd_data_kernel` would otherwise match the library pattern `conv_bwd_data`)
+    ("dpamd depthwise conv", r"dwconv"),
     ("conv fwd (MIOpen igemm)", r"igemm_fwd"),
     ("conv dgrad (MIOpen/CK)", r"igemm_bwd|conv_bwd_data"),
     ("conv wgrad (MIOpen/CK)", r"igemm_wrw|conv_bwd_weight"),
     ("dpamd conv wgrad", r"conv_wgrad"),
     ("dpamd conv fwd/dgrad igemm", r"dp_conv|igemm_kernel|conv_igemm"),
-    ("dpamd batchnorm", r"bn_stats_kernel|bn_apply_kernel|bn_bwd"),
+    ("dpamd batchnorm", r"bn_stats_kernel|bn_apply_kernel|bn_bwd|bn_fold"),
     ("dpamd attention", r"pam_|cam_"),
     ("dpamd data path", r"affine_augment|mask_bbox|compose_crop|extreme_points|nellipse"),
     ("dpamd misc", r"dp_|softmax_ce|upsample_ce|bilinear_|maxpool|avgpool|sgd_flat|affine_aug|confusion|dwconv|weight_transpose|pad_channels|p2p_"),
