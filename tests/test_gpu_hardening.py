@@ -1,0 +1,238 @@
+"""Harder checks of the hand-written kernels (VERDICT r1 "harden the tests"):
+
+* headline problems of the packaged tile table (``ops/tuned_gfx950.json``: DeepLabv3+ R101 at 513x513) at batch 32
+  through forward / data gradient / weight gradient WITH the table's tile configuration, judged by per-channel
+  relative error and cosine similarity against an fp32 CPU convolution (not by one max-over-tensor number);
+* an input beyond the second-generation kernels' 32-bit offsets (> 2 GiB) takes the first-generation kernels and
+  gives the same numbers as the per-image launches;
+* one training step of DeepLabv3+ Xception-65 (output stride 8) and of DeepLabv3+ R101 against the same model in
+  fp32 on the CPU.
+
+Run on an MI355X: ``pytest -m gpu``."""
+import copy
+import json
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from distributedpytorch_amd import ops
+from distributedpytorch_amd.ops import _backend as B
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+_TABLE = os.path.join(os.path.dirname(ops.__file__), "tuned_gfx950.json")
+
+
+def _nhwc(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def cosine(a, b):
+    a, b = a.detach().double().flatten().cpu(), b.detach().double().flatten().cpu()
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def channel_rel(a, b, dim=1):
+    """Worst per-channel max error relative to that channel's own largest reference magnitude (a quiet channel
+    is not hidden behind a loud one); channels whose reference is ~0 everywhere are judged against the tensor."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    dims = [d for d in range(a.dim()) if d != dim]
+    err = (a - b).abs().amax(dim=dims)
+    mag = b.abs().amax(dim=dims).clamp_min(1e-2 * float(b.abs().max()) + 1e-30)
+    return float((err / mag).max())
+
+
+def channel_cos(a, b, dim=1):
+    a = a.detach().double().cpu().movedim(dim, 0).flatten(1)
+    b = b.detach().double().cpu().movedim(dim, 0).flatten(1)
+    c = (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1)).clamp_min(1e-30)
+    live = b.norm(dim=1) > 1e-6 * b.norm()
+    return float(c[live].min())
+
+
+# (hi, cin, cout, k, stride, pad, dil, with_stats, check_wgrad): fwd problems of the table (its batch is 128)
+HEADLINE = [
+    (129, 64, 256, 1, 1, 0, 1, True, True),        # layer1 expand
+    (129, 128, 128, 3, 2, 1, 1, True, True),       # layer2 strided 3x3 (the table sends it to the first generation)
+    (65, 128, 128, 3, 1, 1, 1, True, True),        # layer2 3x3
+    (33, 512, 512, 3, 1, 2, 2, True, False),       # layer4 atrous 3x3
+    (33, 2048, 256, 3, 1, 12, 12, True, False),    # ASPP branch, K = 18432, taps outside the map
+    (33, 1024, 2048, 1, 1, 0, 1, True, True),      # layer4 projection
+    (129, 304, 256, 3, 1, 1, 1, True, False),      # decoder conv on the concat (Cin = 304)
+]
+
+
+def _table_cfg(n, hi, cin, ho, cout, k, stride, pad, dil, stats):
+    with open(_TABLE) as f:
+        table = json.load(f)
+    key = json.dumps([n, hi, hi, cin, ho, ho, cout, k, k, stride, 1, [pad, pad], [dil, dil], False, stats])
+    return table.get(key)
+
+
+@pytest.mark.parametrize("case", HEADLINE)
+def test_headline_problem_at_batch_32(case):
+    from distributedpytorch_amd.ops import _hip_conv
+    hi, cin, cout, k, stride, pad, dil, stats, check_wgrad = case
+    n = 32
+    ho = (hi + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    cfg = _table_cfg(128, hi, cin, ho, cout, k, stride, pad, dil, stats)
+    assert cfg is not None, "problem missing from the packaged tile table"
+    torch.manual_seed(hi * 7 + cin)
+    # per-channel scales over two decades: a max-over-tensor tolerance would hide errors in the quiet channels
+    x = torch.randn(n, cin, hi, hi) * (10 ** torch.linspace(-1, 1, cin)).view(1, cin, 1, 1)
+    x = x.to(torch.bfloat16)
+    w = (torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k) *
+         (10 ** torch.linspace(-1, 0.5, cout)).view(cout, 1, 1, 1)).to(torch.bfloat16)
+    gy = torch.randn(n, cout, ho, ho).to(torch.bfloat16)
+    sel = [0, n - 1]
+
+    # ---- raw kernel with the table's tile configuration (forward + fused statistics) ----
+    xg, wg = _nhwc(x.to(DEV)), _nhwc(w.to(DEV))
+    st = torch.zeros(4, 2, cout, device=DEV) if stats else None
+    y = _hip_conv.igemm(xg, wg, (ho, ho), stride, 1, (pad, pad), (dil, dil), None, st, cfg=cfg)
+    xr = x[sel].float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad, dil)
+    assert cosine(y[sel], yr) > 0.99995
+    assert channel_cos(y[sel], yr) > 0.9995
+    assert channel_rel(y[sel], yr) < 2e-2
+    if stats:
+        s = st.sum(0)
+        yf = y.float()
+        assert channel_rel(s[0], yf.sum(dim=(0, 2, 3)), dim=0) < 2e-2
+        assert channel_rel(s[1], (yf * yf).sum(dim=(0, 2, 3)), dim=0) < 2e-2
+
+    # ---- autograd path: data gradient (two images against the CPU) and weight gradient (whole batch) ----
+    xh = xg.clone().requires_grad_(True)
+    wh = w.float().to(DEV).requires_grad_(True)
+    yh = ops.conv2d(xh, wh, None, stride, pad, dil)
+    yh.backward(_nhwc(gy.to(DEV)))
+    yr.backward(gy[sel].float())
+    assert cosine(xh.grad[sel], xr.grad) > 0.9999
+    assert channel_cos(xh.grad[sel], xr.grad) > 0.999
+    assert channel_rel(xh.grad[sel], xr.grad) < 2e-2
+    if check_wgrad:
+        wfull = w.float().requires_grad_(True)
+        F.conv2d(x.float(), wfull, None, stride, pad, dil).backward(gy.float())
+        assert cosine(wh.grad, wfull.grad) > 0.9999
+        assert channel_cos(wh.grad, wfull.grad, dim=0) > 0.999       # per output channel
+        assert channel_cos(wh.grad, wfull.grad, dim=1) > 0.999       # per input channel
+        assert channel_rel(wh.grad, wfull.grad, dim=0) < 2e-2
+
+
+def test_conv_beyond_2gib_takes_first_generation_kernels():
+    """8 x 128 x 1025 x 1025 bf16 = 2.15 GB: past the 32-bit byte offsets of the second-generation kernels
+    (dp_conv_igemm2 returns -4).  The whole-batch results must equal the per-image launches (269 MB each: second
+    generation) and an fp32 CPU convolution of sampled rows."""
+    from distributedpytorch_amd.ops import _hip_conv
+    n, cin, cout, hw = 8, 128, 16, 1025
+    torch.manual_seed(2)
+    x = _nhwc(torch.randn(n, cin, hw, hw, device=DEV, dtype=torch.bfloat16))
+    assert x.numel() * 2 >= (1 << 31) - (1 << 24)
+    for k, pad in ((1, 0), (3, 1)):
+        w = _nhwc((torch.randn(cout, cin, k, k, device=DEV) / math.sqrt(cin * k * k)).to(torch.bfloat16))
+        lib = B.lib()
+        from distributedpytorch_amd.ops._hip_conv import _lib
+        y_probe = torch.empty(n, cout, hw, hw, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        rc = _lib().dp_conv_igemm2(B.ptr(x), B.ptr(w), B.ptr(y_probe), None, None, 1, n, hw, hw, cin, hw, hw, cout, k, k,
+                                   1, 1, pad, pad, 1, 1, cout, 1, B.stream_ptr())
+        assert rc == -4, f"second-generation kernel accepted a {x.numel() * 2 / 2**30:.2f} GiB input (rc {rc})"
+        xh = x.detach().requires_grad_(True)
+        wh = w.float().requires_grad_(True)
+        y = ops.conv2d(xh, wh, None, 1, pad, 1)
+        gy = _nhwc(torch.randn_like(y))
+        y.backward(gy)
+        # per-image launches
+        dw_sum = torch.zeros_like(wh)
+        for i in (0, n - 1):
+            xi = x[i:i + 1].detach().clone(memory_format=torch.channels_last).requires_grad_(True)
+            wi = w.float().requires_grad_(True)
+            yi = ops.conv2d(xi, wi, None, 1, pad, 1)
+            yi.backward(gy[i:i + 1].clone(memory_format=torch.channels_last))
+            assert channel_rel(y[i:i + 1], yi) < 1e-2 and cosine(y[i:i + 1], yi) > 0.99999
+            assert channel_rel(xh.grad[i:i + 1], xi.grad) < 1e-2 and cosine(xh.grad[i:i + 1], xi.grad) > 0.99999
+        wall = torch.zeros_like(wh)
+        for i in range(n):
+            wi = w.float().requires_grad_(True)
+            xi = x[i:i + 1].detach().clone(memory_format=torch.channels_last)
+            ops.conv2d(xi, wi, None, 1, pad, 1).backward(gy[i:i + 1].clone(memory_format=torch.channels_last))
+            wall += wi.grad
+        assert cosine(wh.grad, wall) > 0.9999 and channel_rel(wh.grad, wall, dim=0) < 1e-2
+        # fp32 CPU convolution of a strip of the last image
+        rows = slice(500, 520)
+        xs = x[n - 1:n, :, rows.start - pad:rows.stop + pad].float().cpu()
+        ys = F.conv2d(xs, w.float().cpu(), None, 1, (0, pad), 1)
+        assert channel_rel(y[n - 1:n, :, rows], ys) < 1.5e-2
+        del xh, y, gy, y_probe
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,kwargs,size", [
+    ("deeplabv3plus_xception65", dict(output_stride=8), 129),
+    ("deeplabv3plus_resnet101", dict(), 257),
+])
+def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
+    """One training step (batch statistics) on the kernels against the same model in fp32 on the CPU's torch path:
+    loss and the gradients of every convolution.
+
+    A random-init residual stack at full gain is chaotic — rounding only the INPUT to bf16 moves the fp32 CPU
+    gradients to a median cosine of 0.42 (X65) / 0.04 (R101) against themselves (tools/diag_model_step.py,
+    gpurun_out/q/diag_*.log) — so the BatchNorm closing each residual branch gets gamma x 0.15 (a network near the
+    identity, as under zero-init-residual).  There the fp32 noise floor is 0.98, the bf16 kernels land at 0.80-0.87
+    with OR without the fused paths, and a wiring error in a fused path shows as fused << plain."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy, _hip_conv, sepconv
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(0)
+    m_cpu = build_model(name, 21, **kwargs).train()
+    with torch.no_grad():
+        for m in m_cpu.modules():
+            if hasattr(m, "running_mean"):
+                m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.3)
+        for k, p in m_cpu.named_parameters():
+            if k.endswith("bn3.weight") or (".rep." in k and k.endswith(".bn.weight") and not k.endswith("sep.bn.weight")):
+                p.mul_(0.15)
+    for m in m_cpu.modules():            # dropout off: the fused counter-based generator is not torch's
+        if isinstance(getattr(m, "p_drop", None), tuple):
+            m.p_drop = (0.0, 0.0)
+        elif hasattr(m, "p_drop"):
+            m.p_drop = 0.0
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, size, size, generator=g)
+    lab = torch.randint(0, 21, (4, 8, 8), generator=g)
+    lab = F.interpolate(lab[:, None].float(), size=(size, size), mode="nearest")[:, 0].long()
+    lab[:, :4] = 255
+    crit = SoftmaxCrossEntropy(255)
+    got = {}
+    for var, fold, prologue in (("fused", True, True), ("plain", False, False)):
+        old = sepconv._FOLD, _hip_conv._BN_PROLOGUE
+        sepconv._FOLD, _hip_conv._BN_PROLOGUE = fold, prologue
+        try:
+            eng = TrainEngine(copy.deepcopy(m_cpu), crit, lr=0.0, momentum=0.0, weight_decay=0.0,
+                              device=torch.device("cuda", 0))
+            loss = crit(eng.ddp(eng.prepare_input(x)), lab.cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            got[var] = (float(loss.detach()), {s.name: s.param.grad.detach().float().cpu().clone()
+                                               for s in eng.ddp.arena.slots})
+        finally:
+            sepconv._FOLD, _hip_conv._BN_PROLOGUE = old
+    l_cpu = crit(m_cpu(x), lab)
+    l_cpu.backward()
+    ref = {k: p.grad.detach().float() for k, p in m_cpu.named_parameters() if p.grad is not None}
+    names = [k for k in ref if ref[k].dim() == 4 and float(ref[k].norm()) > 1e-7]
+
+    def summary(a):
+        cs = [cosine(a[k], ref[k]) for k in names]
+        return cs[-1], sorted(cs)[len(cs) // 2]
+
+    (lf, gf), (lp, gp) = got["fused"], got["plain"]
+    last_f, med_f = summary(gf)
+    last_p, med_p = summary(gp)
+    print(name, "loss cpu/fused/plain", float(l_cpu.detach()), lf, lp, "last-layer cos", last_f, last_p, "median cos", med_f, med_p)
+    assert abs(lf - float(l_cpu)) < 0.02 * abs(float(l_cpu))
+    assert last_f > 0.995 and med_f > 0.7, (last_f, med_f)
+    assert med_f > med_p - 0.06, (med_f, med_p)
