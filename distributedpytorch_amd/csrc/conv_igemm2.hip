@@ -25,6 +25,7 @@
 //     is exact, so the per-lane base and the uniform tap offset stay separable.
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -69,7 +70,21 @@ struct Conv2Args {
     unsigned x_bytes, w_bytes;
     int ablate;             // diagnostics only (dp_conv_set_ablate): 1 = no LDS-DMA in the K loop,
                             // 4 = no fragment reads and no MFMA; results are garbage, the TIME tells the bound
+    int stag_slot, stag_cu, first_round;   // start-time stagger of the first round of blocks (see the kernel head)
+#ifdef DP_STAMP
+    unsigned long long* dbg;   // diagnostic build only (tools/stamp_conv.py): 7 s_memtime + 2 s_memrealtime stamps per block (stride 16)
+#endif
 };
+
+// Phase stamps of a block's life (diagnostic build -DDP_STAMP, never in libdpamd_hip.so): scalar s_memtime
+// reads kept in SGPRs, written by one lane at the very end.
+#ifdef DP_STAMP
+#define DP_STAMP_DECL unsigned long long stamp_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DP_STAMP_AT(i) stamp_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define DP_STAMP_DECL
+#define DP_STAMP_AT(i)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -111,6 +126,13 @@ __device__ __forceinline__ void lds_read16(i32x4v& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
 
+// rows per batch of the fused BN-backward store loop: three loads per row, all issued before the first is consumed.
+// 8 (6) rows instead of 4 (3): -4...-7 % on the 1x1 data gradients of ResNet-101 (gpurun_out/ad: the loop moves
+// 4 tensors per output and runs at the bytes in flight per CU until it reaches the HBM rate)
+#ifndef DP_BN_GRP
+#define DP_BN_GRP(NR) ((NR) % 8 == 0 ? 8 : ((NR) % 6 == 0 ? 6 : ((NR) % 4 == 0 ? 4 : ((NR) % 3 == 0 ? 3 : ((NR) % 2 == 0 ? 2 : 1)))))
+#endif
+
 // PIPE: fragment reads are software-pipelined against the MFMAs by hand (see the K loop).
 template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64, bool PIPE = true>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2Args p) {
@@ -132,6 +154,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DP_STAMP_DECL;
+#ifdef DP_STAMP
+    stamp_[7] = __builtin_amdgcn_s_memrealtime();
+    stamp_[9] = __builtin_amdgcn_s_getreg(63492);    // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+    stamp_[10] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+#endif
+    // ---- de-phasing ----
+    // Blocks that share a CU (and the CUs of the chip) all start together and, doing identical work, stay in
+    // phase: everybody fills, everybody runs the K loop (L2->LDS and MFMA busy, HBM idle), everybody stores
+    // (HBM saturated, MFMA idle) — measured with tools/stamp_conv.py.  Delaying the blocks of the FIRST round by
+    // a fraction of a block's life, by wave slot (co-resident blocks) and by CU parity, makes later rounds
+    // overlap one block's epilogue with another's K loop; later blocks inherit the offset of the block whose
+    // slot they take.
+    if (p.stag_slot | p.stag_cu) {
+        if ((int)blockIdx.x < p.first_round) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(63492);
+            constexpr int WPS = T / 256;                              // waves of one block per SIMD
+            const int units = (int)((hw & 15u) / WPS) * p.stag_slot + (int)((hw >> 8) & 3u) * p.stag_cu;
+            for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+        }
+    }
+    DP_STAMP_AT(0);
 
     // ---- XCD-aware tile mapping (bijective for any grid size) ----
     const int nwg = gridDim.x;
@@ -281,6 +325,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     const int ch0 = ((q ^ fsw) << 4), ch1 = (((4 + q) ^ fsw) << 4);      // ch1: second half of a 64-wide step
 
     // ---- prologue: NST-1 stages in flight ----
+    DP_STAMP_AT(1);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s < ksteps) issue_stage(s);
@@ -294,6 +339,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of the buffer about to be refilled are done
         __builtin_amdgcn_s_barrier();
+#ifdef DP_STAMP
+        if (t == 0) DP_STAMP_AT(2);
+#endif
         if (t + NST - 1 < ksteps && !(p.ablate & 1)) {
             int ib = buf + NST - 1;
             if (ib >= NST) ib -= NST;
@@ -374,6 +422,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // all waves done reading operand tiles; LDS is reused for the epilogue
+    DP_STAMP_AT(3);
 
     // ---- epilogue ----
     const bool do_stats = p.stats != nullptr;                                // uniform
@@ -417,6 +466,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         }
     }
     __syncthreads();
+    DP_STAMP_AT(4);
     if (do_stats) {
         // replica = tile_m mod R spreads the per-channel atomics of a large map over R cache lines
         float* dst = p.stats + (long)(tile_m % p.stat_reps) * 2 * p.Cout;
@@ -441,28 +491,55 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                 rsc[j] = okc ? p.res_scale[gcol + j] : 1.f;
                 rsh[j] = okc ? p.res_shift[gcol + j] : 0.f;
             }
+            if (p.res == nullptr) {
 #pragma unroll 4
-            for (int r0 = 0; r0 < BM; r0 += RPP) {
-                const int row = r0 + rsub;
-                const int m = m0 + row;
-                if (m < p.M && gcol < p.Cout) {
-                    const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
-                    uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    if (p.res) {
+                for (int r0 = 0; r0 < BM; r0 += RPP) {
+                    const int row = r0 + rsub;
+                    const int m = m0 + row;
+                    if (m < p.M && gcol < p.Cout) {
+                        const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
+                        *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                }
+            } else {
+                // residual (+ per-channel affine) added on the way out.  The loads of a whole batch of RG rows are
+                // issued before the first is consumed: with one load per row in flight the loop was a chain of
+                // exposed memory round trips (tools/stamp_conv.py: 14-16 us of a 256x256 block's 45 us against
+                // 2.2 us for the plain store loop), i.e. bound by the bytes in flight per CU, not by HBM.
+                const bf16_raw* __restrict__ resp = p.res;
+                bf16_raw* __restrict__ yout = p.y;
+                const bool affine = p.res_scale != nullptr;       // uniform
+                constexpr int NR = BM / RPP;
+                constexpr int RG = NR % 8 == 0 ? 8 : (NR % 6 == 0 ? 6 : (NR % 4 == 0 ? 4 : (NR % 3 == 0 ? 3 : (NR % 2 == 0 ? 2 : 1))));
+                const bool col_ok = gcol < p.Cout;
+                for (int r0 = 0; r0 < BM; r0 += RG * RPP) {
+                    uint4 vr[RG];
+                    bool ok[RG];
+#pragma unroll
+                    for (int g = 0; g < RG; ++g) {
+                        const int m = m0 + r0 + g * RPP + rsub;
+                        ok[g] = (m < p.M) && col_ok;
+                        vr[g] = ok[g] ? *reinterpret_cast<const uint4*>(resp + (long)m * p.ldres + gcol) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < RG; ++g) {
+                        if (!ok[g]) continue;
+                        const int row = r0 + g * RPP + rsub;
+                        const uint2 lo = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(smem + row * C_LD + cpiece * 16 + 8);
                         float a[8], b[8];
-                        unpack8(o, a);
-                        unpack8(*reinterpret_cast<const uint4*>(p.res + (long)m * p.ldres + gcol), b);
-                        if (p.res_scale) {               // uniform
+                        unpack8(make_uint4(lo.x, lo.y, hi.x, hi.y), a);
+                        unpack8(vr[g], b);
+                        if (affine) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) a[j] += fmaf(b[j], rsc[j], rsh[j]);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) a[j] += b[j];
                         }
-                        o = pack8(a);
+                        *reinterpret_cast<uint4*>(yout + (long)(m0 + row) * p.ldy + gcol) = pack8(a);
                     }
-                    *reinterpret_cast<uint4*>(p.y + (long)m * p.ldy + gcol) = o;
                 }
             }
         } else {
@@ -485,7 +562,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                 s1[j] = 0.f; s2[j] = 0.f;
             }
             constexpr int NR = BM / RPP;
-            constexpr int GRP = NR % 4 == 0 ? 4 : (NR % 3 == 0 ? 3 : (NR % 2 == 0 ? 2 : 1));
+            constexpr int GRP = DP_BN_GRP(NR);
             for (int r0 = 0; r0 < BM; r0 += GRP * RPP) {
                 uint4 vx[GRP], va[GRP], vr[GRP];
                 bool ok[GRP];
@@ -549,6 +626,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             }
         }
     }
+#ifdef DP_STAMP
+    DP_STAMP_AT(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DP_STAMP_AT(6);
+    stamp_[8] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) p.dbg[(long)blockIdx.x * 16 + i] = stamp_[i];
+    }
+#endif
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, int MINW, int BK = 64>
@@ -566,6 +653,19 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static const bool pipe = !(getenv("DPAMD_CONV_PIPE") && atoi(getenv("DPAMD_CONV_PIPE")) == 0);
+    if (p.stag_slot | p.stag_cu) {
+        static int slots = 0;                      // resident blocks of this instantiation on the whole chip
+        if (!slots) {
+            int bpc = 0, dev = 0, cus = 256;
+            const void* kf = unit ? (const void*)conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK>
+                                  : (const void*)conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false, BK>;
+            (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kf, T, lds) != hipSuccess || bpc < 1) bpc = 1;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            slots = bpc * cus;
+        }
+        p.first_round = slots;
+    }
     if (!pipe) {
         if (unit) {
             auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK, false>;
@@ -633,9 +733,19 @@ thread_local int t_bn_reps = 0;
 thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
 thread_local const float* t_res_affine[2] = {nullptr, nullptr};   // set by dp_conv_igemm2ra
 int g_ablate = 0;
+int g_stag_slot = -1, g_stag_cu = -1;            // -1: read DPAMD_CONV_STAGGER ("slot,cu", units of 1024 cycles) once
+#ifdef DP_STAMP
+unsigned long long* g_dbg = nullptr;
+#endif
 }  // namespace
 
 DP_EXPORT int dp_conv_set_ablate(int mask) { g_ablate = mask; return 0; }
+DP_EXPORT int dp_conv_set_stagger(int slot_units, int cu_units) {
+    g_stag_slot = slot_units < 0 ? 0 : slot_units; g_stag_cu = cu_units < 0 ? 0 : cu_units; return 0;
+}
+#ifdef DP_STAMP
+DP_EXPORT int dp_conv_set_dbg(void* buf) { g_dbg = (unsigned long long*)buf; return 0; }
+#endif
 
 // + res: optional [N*Ho*Wo, ldres] bf16 tensor added to the output (not part of the fused statistics)
 DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float* bias, float* stats, int stat_reps,
@@ -668,6 +778,16 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
     p.ldx = ldx;
     p.ablate = g_ablate;
+    if (g_stag_slot < 0) {
+        int a = 0, b = 0;
+        const char* e = getenv("DPAMD_CONV_STAGGER");
+        if (e) sscanf(e, "%d,%d", &a, &b);
+        g_stag_slot = a < 0 ? 0 : a; g_stag_cu = b < 0 ? 0 : b;
+    }
+    p.stag_slot = g_stag_slot; p.stag_cu = g_stag_cu; p.first_round = 0;
+#ifdef DP_STAMP
+    p.dbg = g_dbg;
+#endif
     p.smul = smul; p.sdl = sdiv == 1 ? 0 : (sdiv == 2 ? 1 : 2);
     p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
     p.ldy = ldy;
