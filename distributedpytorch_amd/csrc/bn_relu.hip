@@ -184,6 +184,9 @@ struct ApplyArgs {
     Drop drop;
     long y_ld8;   // output row stride in 16-byte chunks (C/8, or more when y is a channel slice of a
                   // wider concat buffer: the producer writes its slice in place, no cat kernel)
+    unsigned char* mask;   // optional [M][C/8]: bit j of byte (row, chunk) = output element j is positive.  The
+                           // consumer's data-gradient kernel masks with it instead of re-reading the whole
+                           // activation (1/16 of the bytes; residual blocks, where the mask cannot be recomputed)
 };
 
 template <bool FROM_STATS>
@@ -247,6 +250,13 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(ApplyArgs a) {
             if (has_res) { y0 += g0[j]; y1 += g1[j]; }
             if (a.relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
             f0[j] = y0; f1[j] = y1;
+        }
+        if (a.mask) {
+            unsigned b0 = 0, b1 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { b0 |= (unsigned)(f0[j] > 0.f) << j; b1 |= (unsigned)(f1[j] > 0.f) << j; }
+            a.mask[q0] = (unsigned char)b0;
+            if (second) a.mask[q1] = (unsigned char)b1;
         }
         if (a.drop.thr) {
             const unsigned k0 = drop_keep8(q0, a.drop), k1 = drop_keep8(q1, a.drop);
@@ -598,6 +608,13 @@ inline Drop take_drop() {
     return d;
 }
 
+thread_local unsigned char* t_mask_out = nullptr;
+inline unsigned char* take_mask() {
+    unsigned char* m = t_mask_out;
+    t_mask_out = nullptr;
+    return m;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -628,6 +645,13 @@ DP_EXPORT int dp_bn_set_sum_replicas(int nrep, long rep_stride) {
     return 0;
 }
 
+// The next dp_bn_apply_stats launch of this thread also writes the positivity bit mask of its output
+// ([M][C/8] bytes, ApplyArgs::mask).
+DP_EXPORT int dp_bn_set_mask_out(void* mask) {
+    t_mask_out = (unsigned char*)mask;
+    return 0;
+}
+
 // thr16: round(p * 65536) in [1, 65535]; consumed (and cleared) by the next launch listed above
 DP_EXPORT int dp_bn_set_dropout(unsigned thr16, unsigned long long seed) {
     if (thr16 == 0 || thr16 > 65535u) return -1;
@@ -645,8 +669,10 @@ DP_EXPORT int dp_bn_apply_stats(const void* x, const void* res, void* y, long M,
     // armed per-launch state (dp_bn_set_ld / dp_bn_set_dropout) is consumed even if this call is rejected
     const long ld8_ = take_ld8(C > 0 ? C : 8);
     const Drop drop_ = take_drop();
+    unsigned char* mask_ = take_mask();
     if (C % 8 != 0 || M <= 0) return -1;
     ApplyArgs a{};
+    a.mask = mask_;
     a.x = (const bf16_raw*)x; a.res = (const bf16_raw*)res; a.y = (bf16_raw*)y; a.M = M; a.C = C;
     a.sum = sum; a.sq = sq; a.weight = weight; a.bias = bias;
     a.mean_out = mean_out; a.invstd_out = invstd_out; a.running_mean = running_mean; a.running_var = running_var;

@@ -53,6 +53,8 @@ struct Conv2Args {
     // reductions BN backward needs — so the separate bn_bwd_reduce pass (dy, x, y re-read) is gone.
     const bf16_raw* bnx;    // [M, Cout] pre-BN activations (x̂ = (bnx − mean)·rstd) or null
     const bf16_raw* bna;    // [M, Cout] a itself (mask source) or null: mask = bnx·scale + shift > 0
+    const unsigned char* bnmask;   // [M, Cout/8] positivity bits of a (bn_relu.hip, ApplyArgs::mask): the mask source
+                            //   of a residual block's output at 1/16 of the bytes of bna; takes precedence over bna
     const float* bn_mean; const float* bn_rstd;   // [Cout]
     const float* bn_w; const float* bn_b;         // [Cout] affine parameters or null (1, 0)
     float* bnsums;          // [bn_reps, 2, Cout]
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             // are issued before the first is consumed (the store loop is otherwise one exposed memory
             // round trip per row)
             const bf16_raw* __restrict__ bnx = p.bnx;
-            const bf16_raw* __restrict__ bna = p.bna;
+            const unsigned char* __restrict__ bnm = p.bnmask;
+            const bf16_raw* __restrict__ bna = bnm ? nullptr : p.bna;
             const bf16_raw* __restrict__ resp = p.res;
             bf16_raw* __restrict__ yout = p.y;
             const bool col_ok = gcol < p.Cout;
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             constexpr int GRP = DP_BN_GRP(NR);
             for (int r0 = 0; r0 < BM; r0 += GRP * RPP) {
                 uint4 vx[GRP], va[GRP], vr[GRP];
+                unsigned vm[GRP];
                 bool ok[GRP];
 #pragma unroll
                 for (int g = 0; g < GRP; ++g) {
@@ -573,6 +577,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                     const long off = (long)m * p.Cout + gcol;
                     vx[g] = ok[g] ? *reinterpret_cast<const uint4*>(bnx + off) : make_uint4(0, 0, 0, 0);
                     va[g] = (ok[g] && bna) ? *reinterpret_cast<const uint4*>(bna + off) : make_uint4(0, 0, 0, 0);
+                    vm[g] = (ok[g] && bnm) ? bnm[off >> 3] : 0u;
                     vr[g] = (ok[g] && resp) ? *reinterpret_cast<const uint4*>(resp + (long)m * p.ldres + gcol)
                                             : make_uint4(0, 0, 0, 0);
                 }
@@ -589,7 +594,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                     unpack8(vr[g], b);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a[j] += b[j];
-                    if (bna) {
+                    if (bnm) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[j] = (vm[g] >> j) & 1u ? a[j] : 0.f;
+                    } else if (bna) {
                         float av[8];
                         unpack8(va[g], av);
 #pragma unroll
@@ -727,6 +735,7 @@ namespace {
 // set by dp_conv_igemm2b for the launch it forwards to dp_conv_igemm2r (host-side, same thread)
 thread_local const void* t_bnx = nullptr;
 thread_local const void* t_bna = nullptr;
+thread_local const void* t_bnmask = nullptr;   // set by dp_conv_set_bnmask for the next dp_conv_igemm2b
 thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
@@ -770,6 +779,7 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.res_scale = res ? t_res_affine[0] : nullptr; p.res_shift = res ? t_res_affine[1] : nullptr;
     if (p.res_scale && t_bnx) return -1;
     p.bnx = (const bf16_raw*)t_bnx; p.bna = (const bf16_raw*)t_bna; p.bnsums = t_bnsums;
+    p.bnmask = (const unsigned char*)t_bnmask;
     p.bn_mean = t_bnp[0]; p.bn_rstd = t_bnp[1]; p.bn_w = t_bnp[2]; p.bn_b = t_bnp[3];
     p.bn_reps = t_bn_reps < 1 ? 1 : t_bn_reps;
     if (p.bnx && (stats || bias || ldy != Cout)) return -1;
@@ -819,6 +829,11 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     }
 }
 
+namespace { thread_local const void* t_bnmask_next = nullptr; }
+// The next dp_conv_igemm2b launch of this thread takes its ReLU mask from these positivity bits ([N*Ho*Wo, Cout/8]
+// bytes, written by the BatchNorm apply kernel) instead of from bna / a recomputation.
+DP_EXPORT int dp_conv_set_bnmask(const void* mask) { t_bnmask_next = mask; return 0; }
+
 // Data-gradient launch with the fused BN+ReLU backward prologue (see Conv2Args::bnx).  bnx / bna:
 // [N*Ho*Wo, Cout] bf16 (bna may be null: mask recomputed from bnx), bn_mean / bn_rstd / bn_w / bn_b:
 // fp32 [Cout] (bn_w, bn_b may be null), bnsums: fp32 [bn_reps, 2, Cout], zero-initialised.
@@ -827,13 +842,16 @@ DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int 
                               int dil_w, int cfg, const void* res, const void* bnx, const void* bna,
                               const float* bn_mean, const float* bn_rstd, const float* bn_w, const float* bn_b,
                               float* bnsums, int bn_reps, hipStream_t st) {
+    const void* mask_ = t_bnmask_next;      // armed state is consumed even if this call is rejected
+    t_bnmask_next = nullptr;
     if (!bnx || !bn_mean || !bn_rstd || !bnsums || bn_reps < 1) return -1;
     if (((uintptr_t)bnx | (uintptr_t)bna) & 15) return -3;
+    t_bnmask = mask_;
     t_bnx = bnx; t_bna = bna; t_bnsums = bnsums; t_bn_reps = bn_reps;
     t_bnp[0] = bn_mean; t_bnp[1] = bn_rstd; t_bnp[2] = bn_w; t_bnp[3] = bn_b;
     const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
                                    pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
-    t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0;
+    t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0; t_bnmask = nullptr;
     t_bnp[0] = t_bnp[1] = t_bnp[2] = t_bnp[3] = nullptr;
     return rc;
 }

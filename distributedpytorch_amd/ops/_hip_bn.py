@@ -27,6 +27,7 @@ def _lib():
         lib.dp_bn_bwd_apply.argtypes = [c_void_p] * 5 + [c_long, c_int] + [c_void_p] * 6 + [c_float, c_int] + \
             [c_void_p] * 4 + [c_float, c_void_p]
         lib.dp_bn_set_ld.argtypes = [c_long]
+        lib.dp_bn_set_mask_out.argtypes = [c_void_p]
         lib.dp_bn_set_sum_replicas.argtypes = [c_int, c_long]
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         lib.dp_bn_fold.argtypes = [c_void_p, c_int, c_long] + [c_void_p] * 4 + [c_float] * 3 + [c_void_p] * 7 + \
@@ -131,7 +132,7 @@ def _arm_dropout(dropout) -> None:
 
 
 def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var, count, eps, momentum, relu,
-                     replicas=None, dropout=None, out=None):
+                     replicas=None, dropout=None, out=None, mask_out=None):
     """Training form: finalises mean/invstd/running stats inside the apply kernel.
     ``replicas``: optional fp32 [R, 2, C] partial statistics from the conv epilogue (then ``s``/``ss``
     are ignored and the kernel sums the R replicas itself).  Returns (y, mean, invstd)."""
@@ -159,6 +160,12 @@ def apply_from_stats(x, s, ss, weight, bias, residual, running_mean, running_var
     mi = torch.empty(2, C, dtype=torch.float32, device=x.device)
     _arm_dropout(dropout)
     _arm_ld(ld, C)
+    if mask_out is not None:
+        # uint8 [M, C/8]: positivity bits of the output (csrc/bn_relu.hip, ApplyArgs::mask)
+        if mask_out.dtype != torch.uint8 or mask_out.numel() != M * (C // 8) or not mask_out.is_contiguous() \
+                or mask_out.device != x.device:
+            raise ValueError("mask_out must be a contiguous uint8 tensor of M * C/8 bytes on x's device")
+        B.check(_lib().dp_bn_set_mask_out(B.ptr(mask_out)), "bn_set_mask_out")
     B.check(_lib().dp_bn_apply_stats(B.ptr(x), B.ptr(residual), B.ptr(y), M, C, B.ptr(s), B.ptr(ss),
                                      B.ptr(weight), B.ptr(bias), B.ptr(mi[0]), B.ptr(mi[1]),
                                      B.ptr(running_mean), B.ptr(running_var), float(count), float(eps),

@@ -33,6 +33,7 @@ def _lib():
         lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
         lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 8 + [I, V]
         lib.dp_conv_igemm2ra.argtypes = [V, V, V] + [I] * 16 + [V] * 4
+        lib.dp_conv_set_bnmask.argtypes = [V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -238,7 +239,13 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
             or not bx.is_contiguous(memory_format=torch.channels_last)):
         return None
     ba = a if holder.get("mask_from_a") else None      # the activation itself = this convolution's input
-    if holder.get("mask_from_a") and ba is None:
+    bits = holder.get("mask_bits") if holder.get("mask_from_a") else None
+    if bits is not None:
+        # positivity bits left by the BatchNorm apply kernel: 1/16 of the bytes of re-reading the activation
+        if bits.dtype != torch.uint8 or bits.numel() != n * ho * wo * (cout // 8) or not bits.is_contiguous():
+            return None
+        ba = None
+    elif holder.get("mask_from_a") and ba is None:
         return None
     if ba is not None and (ba.shape != bx.shape or not ba.is_contiguous(memory_format=torch.channels_last)):
         return None
@@ -252,12 +259,14 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
     # the fused store loop is heavier than the plain one (it reads x and the mask source): its best tile is
     # measured on the fused launch itself
     key = ("dgrad_bn", n, hi, wi, cin, ho, wo, cout, r, s, sdiv, tuple(pad), tuple(dil), residual is not None,
-           ba is not None)
+           ba is not None or bits is not None)
     cfg = _FORCED_CFG if _FORCED_CFG is not None else _TUNED.get(key)
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     reps = stat_replicas(n * ho * wo)
 
     def launch(c, sums_ptr, stream):
+        if bits is not None:
+            _lib().dp_conv_set_bnmask(B.ptr(bits))       # consumed by the launch below
         return _lib().dp_conv_igemm2b(B.ptr(dy), B.ptr(wt), B.ptr(y), n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
                                       pad[0], pad[1], dil[0], dil[1], c, B.ptr(residual), B.ptr(bx), B.ptr(ba),
                                       B.ptr(holder["mean"]), B.ptr(holder["invstd"]), B.ptr(holder.get("w")),

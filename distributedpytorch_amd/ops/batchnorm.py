@@ -28,6 +28,8 @@ import os
 from . import _backend as B
 
 _FUSE_DROPOUT = os.environ.get("DPAMD_FUSE_DROPOUT", "1") != "0"
+# DPAMD_BN_MASK_BITS=0: residual blocks keep no positivity bit mask (the consumer re-reads the activation)
+_MASK_BITS = os.environ.get("DPAMD_BN_MASK_BITS", "1") != "0"
 
 
 # --------------------------------------------------------------------------------------
@@ -159,9 +161,16 @@ class _BatchNormActTrain(torch.autograd.Function):
             # the apply kernel finalises mean / invstd / running statistics itself (block 0)
             w = weight.detach().float().contiguous() if weight is not None else None
             b = bias.detach().float().contiguous() if bias is not None else None
-            y, mean, invstd = _hip_bn.apply_from_stats(x, s, ss, w, b, residual, running_mean, running_var,
-                                                       count, eps, momentum, relu, replicas, dropout, out)
             mask_mode = 0 if not relu else (1 if residual is not None else 2)
+            bits = None
+            if mask_mode == 1 and holder is not None and dropout is None and out is None and _MASK_BITS:
+                # a residual block's output: its ReLU mask cannot be recomputed from the BN input alone, and the
+                # consumer's data-gradient kernel would re-read the whole activation for it — leave 1 bit per
+                # element behind instead (csrc/bn_relu.hip, ApplyArgs::mask)
+                bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+            y, mean, invstd = _hip_bn.apply_from_stats(x, s, ss, w, b, residual, running_mean, running_var,
+                                                       count, eps, momentum, relu, replicas, dropout, out,
+                                                       mask_out=bits)
             if dropout is not None:
                 assert relu and residual is None
                 mask_mode, holder = 3, None
@@ -173,7 +182,8 @@ class _BatchNormActTrain(torch.autograd.Function):
                 # (never a reference to y itself: y carries this dict as an attribute, a y -> dict -> y
                 # cycle keeps every residual activation alive until Python's cyclic GC gets to it —
                 # measured: peak HBM 232 GiB instead of 28 GiB at B64)
-                holder.update(x=x, mask_from_a=(mask_mode == 1), mean=mean, invstd=invstd, w=w, b=b)
+                holder.update(x=x, mask_from_a=(mask_mode == 1), mean=mean, invstd=invstd, w=w, b=b,
+                              mask_bits=bits)
         else:
             mean = s / count
             var = (ss / count - mean * mean).clamp_min_(0.0)

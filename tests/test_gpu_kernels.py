@@ -683,6 +683,43 @@ def test_dgrad_bn_fused_store_loop_per_tile_config(cfg, k, with_res):
     assert float((sums[1] - s2_ref).abs().max()) < 4e-3 * scale
 
 
+@pytest.mark.parametrize("cfg", [5, 9, 16])
+def test_dgrad_bn_fused_mask_bits_equal_activation_mask(cfg):
+    """The positivity bit mask a residual block's BatchNorm apply kernel leaves behind (csrc/bn_relu.hip,
+    ApplyArgs::mask; 1 bit per element) gives the fused data-gradient store loop (csrc/conv_igemm2.hip,
+    Conv2Args::bnmask) exactly the mask it used to take from re-reading the activation: same dm, same sums;
+    and the bits themselves are [a > 0] of the kernel's own output."""
+    from distributedpytorch_amd.ops import _hip_bn, _hip_conv
+    torch.manual_seed(11)
+    n, cin, cout, h, w = 3, 96, 160, 37, 29
+    wt = _bf(torch.randn(cout, cin, 1, 1, device=DEV) / math.sqrt(cin))
+    dy = _nhwc(_bf(torch.randn(n, cout, h, w, device=DEV)))
+    bx = _nhwc(_bf(torch.randn(n, cin, h, w, device=DEV)))
+    res = _nhwc(_bf(torch.randn(n, cin, h, w, device=DEV)))
+    skip = _nhwc(_bf(torch.randn(n, cin, h, w, device=DEV)))
+    gam, bet = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.2
+    s, ss = _hip_bn.stats(bx)
+    bits = torch.zeros(bx.numel() // 8, dtype=torch.uint8, device=DEV)
+    a, mean, invstd = _hip_bn.apply_from_stats(bx, s.clone(), ss.clone(), gam, bet, res, None, None,
+                                               float(n * h * w), 1e-5, 0.1, True, mask_out=bits)
+    # bit j of byte (pixel, chunk) = element 8*chunk + j of that pixel is positive
+    a_rows = a.permute(0, 2, 3, 1).reshape(-1, cin // 8, 8)
+    want = ((a_rows.float() > 0).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits.view(-1, cin // 8).to(torch.int32), want)
+    wT = _hip_conv.weight_transpose(_nhwc(wt))
+    old = _hip_conv._FORCED_CFG
+    _hip_conv._FORCED_CFG = cfg
+    try:
+        base = dict(x=bx, mask_from_a=True, mean=mean, invstd=invstd, w=gam, b=bet)
+        dm0, p0 = _hip_conv.dgrad_bn_fused(dy, wT, (h, w), 1, (0, 0), (1, 1), skip, dict(base), a)
+        dm0, p0 = dm0.clone(), p0.sum(0).clone()
+        dm1, p1 = _hip_conv.dgrad_bn_fused(dy, wT, (h, w), 1, (0, 0), (1, 1), skip, dict(base, mask_bits=bits), None)
+    finally:
+        _hip_conv._FORCED_CFG = old
+    assert torch.equal(dm0, dm1)
+    assert _rel(p1.sum(0), p0) < 1e-5
+
+
 @pytest.mark.parametrize("C", [64, 728])
 def test_bn_bwd_apply_folds_sum_replicas(C):
     """csrc/bn_relu.hip bn_bwd_apply_kernel: the [R, 2, C] partial sums a data-gradient store loop leaves
