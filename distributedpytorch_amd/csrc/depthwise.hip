@@ -902,10 +902,183 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
     return DP_LAUNCH_STATUS();
 }
 
-// 4 = rolling row window (default), 3 = LDS row tiles, 2 / 1 = the strip / flat mappings
-static const int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 4;
+// ------------------------------------------------------------------------------------------------
+// Fifth generation, weight gradient on the MATRIX cores.  dw[t][c] = sum_p dy[p][c] * x[p + t][c] is, for a group
+// of 16 channels and one tap, the DIAGONAL of the 16x16 product  D[c][c'] = sum_p dy[p][c] * x[p + t][c']  — a GEMM
+// over the pixel index.  15/16 of the MFMA work is thrown away and it is still ~5x cheaper than the packed dot
+// products of dwconv4 MODE 2 (9 x v_mfma_f32_16x16x16_bf16 = 72 cycles per 16 pixels x 16 channels against 72
+// v_perm + 72 v_dot2c for the same), which leaves the kernel where a reduction over two tensors belongs: on the
+// HBM stream (dwconv4 MODE 2: 606 us per 728-channel 65x65 layer at batch 64 for 788 MB).
+//   * x walks through the same rolling row ring as dwconv4; dy gets a ring of its own (2 TS rows) with the SAME row
+//     geometry (rowpx pixels, d columns of physical zero padding on the left), so one pixel index addresses both.
+//   * both operands are pixel-major in LDS ([pixel][64 channels], as they lie in memory) and are needed
+//     channel-major by the MFMA: ds_read_b64_tr_b16 delivers 4 pixels of one channel per lane.  16-byte chunks are
+//     XOR-swizzled by (pixel & 7) through the DMA's SOURCE address (the destination stays lane-linear), which makes
+//     the transposed reads of 8 consecutive pixels conflict-free.
+//   * a row is cut into 16-pixel K chunks; the last chunk of a row whose width is 8 mod 16 overlaps its
+//     predecessor by 8 pixels and zeroes those in the dy fragment.  Padding columns hold dy = 0, so x may be
+//     anything finite there (guard bands before / after the rings are zeroed once).
+//   * 8 waves: wave & 3 = the 16-channel group of the 64-channel slab, wave >> 2 = which of the TS = 2 rows of a step.
+// MEASURED (gpurun_out/ak, 728 channels, 65x65, batch 64, launchers timed alone): 318 us against 222 us for dwconv4
+// MODE 2 — which in isolation already runs at 3.55 TB/s; its 606 us in the training step is the low-priority
+// auxiliary stream sharing the chip, not arithmetic.  The two rings (x and dy) take 112 KiB, so ONE block per CU,
+// and a block that alternates "wait for the rows" / "read + MFMA" has nothing else on its CU to fill the waits:
+// 2.5 TB/s.  Kept selectable (DPAMD_DWCONV_GEN=5) and tested; not the default.
+typedef short s16x4d __attribute__((ext_vector_type(4)));
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+
+struct Dw5W {
+    const bf16_raw* x; const bf16_raw* dy; float* dw;
+    int N, C, H, W, dil, NR, hsplit, rows_split, rowpx;
+    unsigned bytes;
+};
+
+__global__ __launch_bounds__(512) void dwconv5_wgrad_kernel(Dw5W p) {
+    constexpr int TS = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cgw = wave & 3, rs = wave >> 2;
+    const int c0 = blockIdx.y * 64;
+    const int ncg = min(8, (p.C - c0) >> 3);
+    const int n = blockIdx.x / p.hsplit, hs = blockIdx.x - n * p.hsplit;
+    const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
+    const int d = p.dil, W = p.W, NR = p.NR;
+    const int rowb = p.rowpx * 128, ipr = p.rowpx >> 3;
+    unsigned char* xring = smem5 + 1024;
+    unsigned char* dring = xring + NR * rowb;
+    // Reads of x run up to d pixels past either end of a ring row (against dy = 0): everything they can reach — the
+    // guard bands, and ring slots no DMA has filled yet — must hold FINITE values, so the whole allocation is
+    // zeroed once (a block lives for a whole image band).
+    for (int i = tid * 16; i < 2048 + (NR + 2 * TS) * rowb; i += 512 * 16)
+        *reinterpret_cast<uint4*>(smem5 + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.bytes, 0x00020000);
+    const int c8s = (lane & 7) ^ (lane >> 3);          // logical 16-byte chunk this lane fetches into slot lane & 7
+    const unsigned img = (unsigned)(((long)n * p.H * W * p.C + c0 + c8s * 8) * 2);
+    auto stage = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned char* ring, int r_first, int nrows, int row0, int nslots) {
+        for (int i = wave; i < nrows * ipr; i += 8) {
+            const int rr = i / ipr, seg = i - rr * ipr;
+            const int iy = r_first + rr;
+            const int slot = (iy - row0) % nslots;
+            const int px = seg * 8 + (lane >> 3) - d;
+            const bool ok = (c8s < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)W);
+            const unsigned off = img + (unsigned)((iy * W + px) * p.C * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(ring + (long)slot * rowb + seg * 1024), 16,
+                ok ? off : kOOBd, 0, 0, 0);
+        }
+    };
+    // transposed-read geometry: lane 4q + pp of 16-lane group gq supplies pixel 4 gq + q, channels 4 pp .. 4 pp + 3
+    const int gq = lane >> 4, tl = lane & 15, q = tl >> 2, pp = tl & 3;
+    const int kpix = 4 * gq + q;
+    const int chunk = 2 * cgw + (pp >> 1);
+    const unsigned lane_dy = (unsigned)(kpix * 128 + ((chunk ^ (kpix & 7)) << 4) + ((pp & 1) << 3));
+    unsigned lane_x[3];
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2)
+        lane_x[s2] = (unsigned)(kpix * 128 + ((chunk ^ ((kpix + (s2 - 1) * d) & 7)) << 4) + ((pp & 1) << 3));
+    f32x4d acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4d{0.f, 0.f, 0.f, 0.f};
+    const int nch = (p.rowpx + 15) >> 4;
+
+    stage(rx, xring, ya - d, TS + 2 * d, ya - d, NR);
+    stage(rd, dring, ya, TS, ya, 2 * TS);
+    for (int y0 = ya; y0 < yb; y0 += TS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // this step's rows have landed; everyone is done with the rows about to be replaced
+        if (y0 + TS < yb) {
+            stage(rx, xring, y0 + TS + d, TS, ya - d, NR);
+            stage(rd, dring, y0 + TS, TS, ya, 2 * TS);
+        }
+        const int y = y0 + rs;
+        if (y < yb) {                                        // wave-uniform: EXEC stays full for the transposed reads
+            const unsigned char* drow = dring + ((y - ya) % (2 * TS)) * rowb;
+            const unsigned char* xrow[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) xrow[r] = xring + ((y - ya + r * d) % NR) * rowb;
+            for (int ch = 0; ch < nch; ++ch) {
+                int px0 = ch * 16;
+                const bool overlap = px0 + 16 > p.rowpx;     // uniform
+                if (overlap) px0 = p.rowpx - 16;
+                s16x4d a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4d*)(drow + px0 * 128 + lane_dy));
+                if (overlap && lane < 32) a = s16x4d{0, 0, 0, 0};      // pixels the previous chunk already took
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) {
+                        const s16x4d b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4d*)(xrow[r] + (px0 + (s2 - 1) * d) * 128 + lane_x[s2]));
+                        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[r * 3 + s2], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // the diagonal: lane (gq, tl) holds D[4 gq + j][tl] in register j, so channel tl sits in the lanes with tl >> 2 == gq
+    if ((tl >> 2) == gq) {
+        const int c = c0 + 16 * cgw + tl;
+        if (c < p.C) {
+            const int j = tl & 3;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = j == 0 ? acc[t][0] : (j == 1 ? acc[t][1] : (j == 2 ? acc[t][2] : acc[t][3]));
+                atomicAdd(p.dw + t * p.C + c, v);
+            }
+        }
+    }
+}
+
+inline int launch_dw5w(const void* x, const void* dy, void* dw, int N, int C, int H, int W, int dil, hipStream_t st) {
+    constexpr int TS = 2;
+    const long bytes = (long)N * H * W * C * 2;
+    if (bytes >= (1L << 31) - (1L << 24) || H < TS) return -2;
+    const int rowpx = (W + 2 * dil + 7) / 8 * 8;
+    if (rowpx < 16) return -2;
+    const int NR = 2 * TS + 2 * dil;
+    const long lds = 2048 + (long)(NR + 2 * TS) * rowpx * 128;
+    if (lds > 160 * 1024) return -2;
+    const long slabs = (C + 63) / 64, slots = 256;
+    int best_hs = 1;
+    long best_cost = -1;
+    for (int hs = 1; hs <= 4; ++hs) {
+        const int rows = (H + hs - 1) / hs;
+        if (hs > 1 && rows < 4 * TS) break;
+        const long bands = (H + rows - 1) / rows;
+        const long rounds = (N * slabs * bands + slots - 1) / slots;
+        const long cost = rounds * (rows + 2 * dil);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_hs = hs; }
+    }
+    const int rows_split = ((H + best_hs - 1) / best_hs + TS - 1) / TS * TS;     // bands start on a step boundary
+    const int hsplit = (H + rows_split - 1) / rows_split;
+    const long nb = (long)N * hsplit;
+    if (nb > 0x7fffffffL) return -4;
+    Dw5W p{(const bf16_raw*)x, (const bf16_raw*)dy, (float*)dw, N, C, H, W, dil, NR, hsplit, rows_split, rowpx,
+           (unsigned)bytes};
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)dwconv5_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3((unsigned)nb, (unsigned)slabs), dim3(512), (size_t)lds, st, p);
+    return DP_LAUNCH_STATUS();
+}
+
+// 4 = rolling row window (default); 5 = as 4, with the weight gradient on the matrix cores (opt-in: measured
+// slower, see dwconv5_wgrad_kernel); 3 = LDS row tiles, 2 / 1 = the strip / flat mappings
+static int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 4;
 
 }  // namespace
+
+// tests / tools: select the kernel generation at run time (returns the previous one)
+DP_EXPORT int dp_dwconv_set_gen(int gen) {
+    const int old = kDwGen;
+    if (gen >= 1 && gen <= 5) kDwGen = gen;
+    return old;
+}
 
 DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
                             int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
@@ -970,6 +1143,10 @@ DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int
                                    int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        if (kDwGen >= 5) {
+            const int rc = launch_dw5w(x, dy, dw9, N, C, Hi, Wi, dil, st);
+            if (rc != -2) return rc;
+        }
         if (kDwGen >= 4) {
             const int rc = launch_dw4<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, st);
             if (rc != -2) return rc;

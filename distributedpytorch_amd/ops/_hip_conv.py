@@ -533,6 +533,7 @@ class _ConvIGemm(torch.autograd.Function):
 # kernels for forward and weight gradient, fused BN statistics as everywhere else.
 _DW_WGRAD_AUX = os.environ.get("DPAMD_DW_WGRAD_AUX", "1") != "0"   # depthwise weight gradients on the aux stream
 _SKIP_WGRAD = os.environ.get("DPAMD_SKIP_WGRAD") == "1"     # diagnostics: invalid training, timing only
+_SKIP_DW_WGRAD = os.environ.get("DPAMD_SKIP_DW_WGRAD") == "1"   # same, depthwise weight gradients
 _STEM_WINDOW = 32
 _STEM = os.environ.get("DPAMD_STEM_WINDOW", "1") != "0"
 
@@ -724,7 +725,11 @@ class _DepthwiseConv(torch.autograd.Function):
                     dx += dskip
         elif dskip is not None:
             dx = dskip
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _SKIP_DW_WGRAD:
+            notify = getattr(ctx.weight_param, "_dpamd_on_grad", None)
+            if notify is not None:
+                notify(ctx.weight_param)
+        elif ctx.needs_input_grad[1]:
             dw9 = workspace.zeros(9 * c, x.device).view(9, c)
             wp = ctx.weight_param
             sink = getattr(wp, "_dpamd_grad_sink", None)

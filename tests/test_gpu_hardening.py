@@ -181,7 +181,7 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
     A random-init residual stack at full gain is chaotic — rounding only the INPUT to bf16 moves the fp32 CPU
     gradients to a median cosine of 0.42 (X65) / 0.04 (R101) against themselves (tools/diag_model_step.py,
     gpurun_out/q/diag_*.log) — so the BatchNorm closing each residual branch gets gamma x 0.15 (a network near the
-    identity, as under zero-init-residual).  There the fp32 noise floor is 0.98, the bf16 kernels land at 0.80-0.87
+    identity, as under zero-init-residual).  There the fp32 noise floor is 0.98, the bf16 kernels land at 0.73-0.87
     with OR without the fused paths, and a wiring error in a fused path shows as fused << plain."""
     from distributedpytorch_amd.models import build_model
     from distributedpytorch_amd.ops import SoftmaxCrossEntropy, _hip_conv, sepconv
@@ -234,5 +234,9 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
     last_p, med_p = summary(gp)
     print(name, "loss cpu/fused/plain", float(l_cpu.detach()), lf, lp, "last-layer cos", last_f, last_p, "median cos", med_f, med_p)
     assert abs(lf - float(l_cpu)) < 0.02 * abs(float(l_cpu))
-    assert last_f > 0.995 and med_f > 0.7, (last_f, med_f)
-    assert med_f > med_p - 0.06, (med_f, med_p)
+    # The median moves from run to run of ONE binary (fp32 atomics sum the weight gradients in launch order; a sum
+    # that rounds differently flips ReLU masks downstream): 0.73-0.86 for either variant over seven runs
+    # (gpurun_out/al, am) — so the floor and the fused-vs-plain margin are set from that spread; a wiring error
+    # in a fused path lands far below both (0.04-0.4).
+    assert last_f > 0.995 and med_f > 0.65, (last_f, med_f)
+    assert med_f > med_p - 0.15, (med_f, med_p)

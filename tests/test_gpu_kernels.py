@@ -232,6 +232,35 @@ def test_depthwise(stride, dil, shape):
     assert _rel(wh.grad, wr.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("dil", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (2, 728, 9, 65)])
+def test_depthwise_wgrad_on_matrix_cores(dil, shape):
+    """csrc/depthwise.hip dwconv5_wgrad_kernel (opt-in generation 5): the weight gradient as the diagonal of a
+    16x16 MFMA product over the pixel index — transposed LDS reads of the swizzled x / dy rings, overlapping last
+    chunk, partial 16-channel group — against an fp32 CPU grouped convolution."""
+    from distributedpytorch_amd.ops import _backend as B
+    from distributedpytorch_amd.ops import _hip_conv
+    torch.manual_seed(2)
+    n, c, h, w = shape
+    x = _bf(torch.randn(n, c, h, w, device=DEV))
+    xr = x.float().cpu()
+    wr = torch.zeros(c, 1, 3, 3, requires_grad=True)
+    yr = F.conv2d(xr, wr, None, 1, dil, dil, groups=c)
+    gy = _bf(torch.randn_like(yr)).to(DEV)
+    yr.backward(gy.float().cpu())
+    lib = _hip_conv._lib()
+    old = lib.dp_dwconv_set_gen(5)
+    try:
+        dw9 = torch.zeros(9, c, device=DEV)
+        gy_l, x_l = _nhwc(gy), _nhwc(x)              # named: the launcher takes raw pointers
+        B.check(lib.dp_dwconv_bwd_weight(B.ptr(gy_l), B.ptr(x_l), B.ptr(dw9), n, c, h, w, h, w, 1, dil, dil, dil,
+                                         B.stream_ptr()), "dwconv_bwd_weight")
+        torch.cuda.synchronize()
+    finally:
+        lib.dp_dwconv_set_gen(old)
+    assert _rel(dw9.t().reshape(c, 1, 3, 3), wr.grad) < 1e-2
+
+
 def test_conv_fused_statistics():
     """Σy, Σy² from the conv epilogue (replicated accumulators) == statistics of the output."""
     torch.manual_seed(20)

@@ -51,10 +51,20 @@ def main():
         wg = w.clone().requires_grad_(True)
         y = _hip_conv._DepthwiseConv.apply(xg, wg, w16, (1, 1), (d, d), (d, d))
         dy = torch.randn_like(y)
-        t_f = timeit(lambda: _hip_conv._DepthwiseConv.apply(x, w, w16, (1, 1), (d, d), (d, d)))
-        t_dx = timeit(lambda: torch.autograd.grad(y, xg, dy, retain_graph=True))
-        t_all = timeit(lambda: torch.autograd.grad(y, (xg, wg), dy, retain_graph=True))
-        t_w = t_all - t_dx
+        from distributedpytorch_amd.ops import _backend as B
+        lib = _hip_conv._lib()
+        w9 = w16.reshape(c, 9).t().contiguous()
+        dx = torch.empty_like(x)
+        dw9 = torch.zeros(9, c, device="cuda")
+        hw_ = hw
+        # the launchers themselves, on the current stream (through autograd the weight gradient runs on the auxiliary
+        # stream and the event pair would not see it)
+        t_f = timeit(lambda: lib.dp_dwconv_fwd(B.ptr(x), B.ptr(w9), B.ptr(dx), args.batch, c, hw_, hw_, hw_, hw_, 1, d, d, d,
+                                               B.stream_ptr()))
+        t_dx = timeit(lambda: lib.dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), args.batch, c, hw_, hw_, hw_, hw_, 1,
+                                                     d, d, d, B.stream_ptr()))
+        t_w = timeit(lambda: lib.dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), args.batch, c, hw_, hw_, hw_, hw_, 1,
+                                                      d, d, d, B.stream_ptr()))
         mb = x.numel() * 2 / 1e6
         print(f"{name:18s} x{cnt:2d} {mb:7.1f} MB | fwd {t_f:7.1f} us ({2 * mb / t_f:5.2f} TB/s) | dgrad {t_dx:7.1f} us "
               f"({2 * mb / t_dx:5.2f} TB/s) | wgrad {t_w:7.1f} us ({2 * mb / t_w:5.2f} TB/s)", flush=True)
