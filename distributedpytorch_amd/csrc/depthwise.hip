@@ -12,6 +12,36 @@ namespace {
 
 struct Dw { int N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil; };
 
+// Block -> (image band bx, 64-channel slab by) of the rolling-window kernels, from a 1-D grid.  The slabs of one band
+// are CONSECUTIVE ids of one XCD (the same bijective remap as the dense kernels): with 728 channels a pixel's
+// 128-byte slab segment starts 48 p mod 128 bytes into a cache line, so neighbouring slabs share every line at their
+// seam — on one XCD, launched back to back, the second reader finds the line in that L2 and the two halves of a
+// written line meet there; spread over XCDs each line crosses the fabric twice (728-channel forward 295 us against
+// 311 us for 1024 channels with 40 % more bytes).
+// With whole cache lines per slab segment (C % 64 == 0) there is no seam to share and the band-major order measured
+// SLOWER (1024 channels: 280 -> 317 us, concurrent blocks walk the same DRAM pages): those keep the slab-major order.
+__device__ __forceinline__ void dw_block_coords(int nb, int slabs, int C, int& bx, int& by) {
+    const int total = nb * slabs, L = blockIdx.x;
+    if ((C & 63) == 0) {
+        by = L / nb;
+        bx = L - by * nb;
+        return;
+    }
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    by = v % slabs;
+    bx = v / slabs;
+}
+
+// sum over the 16 lanes of a DPP row (all lanes of the row end up with the total)
+__device__ __forceinline__ float dw_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
 inline int grid_1d(long total, int threads, int cap = 256 * 16) {
     long b = (total + threads - 1) / threads;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -566,9 +596,11 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.y * 64;
+    int bxi, byi;
+    dw_block_coords(p.N * p.hsplit, (p.C + 63) >> 6, p.C, bxi, byi);
+    const int c0 = byi * 64;
     const int ncg = min(8, (p.C - c0) >> 3);
-    const int n = blockIdx.x / p.hsplit, hs = blockIdx.x - n * p.hsplit;
+    const int n = bxi / p.hsplit, hs = bxi - n * p.hsplit;
     const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
     const int d = p.dil, W = p.W, TS = p.TS, NR = p.NR;
     const int cg = tid & 7, pl = tid >> 3;
@@ -825,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                     float v = 0.f;
 #pragma unroll 8
                     for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 16 + e];
-                    float* dst = p.stats + (long)(blockIdx.x % p.stat_reps) * 2 * p.C;
+                    float* dst = p.stats + (long)(bxi % p.stat_reps) * 2 * p.C;
                     atomicAdd(dst + (e >> 3) * p.C + c0 + g * 8 + (e & 7), v);
                 }
             }
@@ -898,7 +930,8 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
     auto kfn = dwconv4_kernel<MODE>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nb, (unsigned)slabs), dim3(256), (size_t)lds, st, p);
+    if (nb * slabs > 0x7fffffffL) return -4;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(nb * slabs)), dim3(256), (size_t)lds, st, p);
     return DP_LAUNCH_STATUS();
 }
 
@@ -1067,6 +1100,231 @@ inline int launch_dw5w(const void* x, const void* dy, void* dw, int N, int C, in
     return DP_LAUNCH_STATUS();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generation 6: forward / data gradient on the MATRIX cores, same rolling row ring and two blocks per CU as
+// generation 4.  For a group of 16 channels the depthwise sum  out[p][c] = sum_t w[t][c] x[p + t][c]  is the dense
+// product  D[c][p] = sum_(t, c') A[c][(t, c')] B[(t, c')][p]  with the DIAGONAL weight matrix
+// A[c][(t, c')] = w[t][c] [c' == c]  and  B[(t, c')][p] = x[p + t][c'] : K = 9 taps x 16 channels = 144 (+16 of
+// padding) = 5 x v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels, 80 MFMA cycles for 256 outputs against ~115
+// VALU instructions per 8 outputs of a lane in dwconv4 (which is VALU-bound: 295 us for a 728-channel 65x65 layer at
+// batch 64, 2.7 TB/s).
+//   * B fragment of lane (pixel j = lane & 15, g = lane >> 4) for MFMA m: the 8 channels (g & 1) * 8 .. + 7 of the
+//     wave's 16-channel group at pixel x0 + j shifted by tap 2 m + (g >> 1): ONE ds_read_b128 from the ring.  The
+//     16-byte chunks of a pixel are XOR-swizzled by (pixel & 7) through the DMA's source address, which makes the 16
+//     lanes x 2 chunk columns of a read group hit 16 different bank quads.
+//   * A fragments (5 x 4 VGPRs per wave) are built once: one nonzero bf16 per lane.
+//   * wave = 16-channel group of the 64-channel slab; a lane ends up with 4 consecutive channels of one pixel
+//     (8-byte stores; the four waves of a block complete a pixel's 128 bytes).
+//   MODE 0: out = conv (+ BatchNorm statistics of out); MODE 1: data gradient with the skip gradient and the previous
+//   BatchNorm+ReLU's backward prologue, as dwconv4 MODE 1 (see Dw4).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv6_kernel(Dw4 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+    typedef __attribute__((ext_vector_type(4))) float f32x4w;
+    typedef __attribute__((ext_vector_type(4))) int i32x4w;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bxi, byi;
+    dw_block_coords(p.N * p.hsplit, (p.C + 63) >> 6, p.C, bxi, byi);
+    const int c0 = byi * 64;
+    const int ncg = min(8, (p.C - c0) >> 3);
+    const int n = bxi / p.hsplit, hs = bxi - n * p.hsplit;
+    const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
+    const int d = p.dil, W = p.W, TS = p.TS, NR = p.NR;
+    const int ipr = p.rowpx >> 3;        // wave-instructions per staged row
+    const int rowb = p.rowpx * 128;      // bytes per ring row
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const int c8s = (lane & 7) ^ (lane >> 3);          // logical 16-byte chunk this lane fetches into slot lane & 7
+    const unsigned img = (unsigned)(((long)n * p.H * W * p.C + c0 + c8s * 8) * 2);
+    auto stage = [&](int r_first, int nrows) {
+        for (int i = wave; i < nrows * ipr; i += 4) {
+            const int rr = i / ipr, seg = i - rr * ipr;
+            const int iy = r_first + rr;
+            const int slot = (iy - (ya - d)) % NR;
+            const int px = seg * 8 + (lane >> 3) - d;
+            const bool ok = (c8s < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)W);
+            const unsigned off = img + (unsigned)((iy * W + px) * p.C * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(smem6 + (long)slot * rowb + seg * 1024), 16,
+                ok ? off : kOOBd, 0, 0, 0);
+        }
+    };
+    // ---- lane geometry ----
+    const int j = lane & 15, g = lane >> 4;
+    const int cw = c0 + 16 * wave;                        // first channel of this wave's group
+    const int chunk = 2 * wave + (g & 1);                 // logical 16-byte chunk of the B fragment
+    // A fragments: lane (i = j, g) holds A[i][k = 8 g + e]; nonzero only at e = i & 7 when (i >> 3) == (g & 1)
+    i32x4w afr[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int tap = 2 * m + (g >> 1);
+        unsigned wv = 0;
+        if (tap < 9 && (j >> 3) == (g & 1) && cw + j < p.C)
+            wv = (unsigned)p.w9[(p.flip ? 8 - tap : tap) * p.C + cw + j];
+        wv <<= 16 * (j & 1);
+        const int dd = (j & 7) >> 1;
+        afr[m] = i32x4w{dd == 0 ? (int)wv : 0, dd == 1 ? (int)wv : 0, dd == 2 ? (int)wv : 0, dd == 3 ? (int)wv : 0};
+    }
+    // B read offsets inside a ring row, per MFMA: pixel shift (s - 1) d and row r of tap 2 m + (g >> 1) (tap 9 = tap 8
+    // again: its weights are zero); the swizzle term depends on (j + shift) & 7 only (x0 is a multiple of 16)
+    int brow[5];                                          // tap row 0 / 1 / 2 of MFMA m's fragment
+    unsigned boff[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        int tap = 2 * m + (g >> 1);
+        tap = tap > 8 ? 8 : tap;
+        const int r = tap / 3, s2 = tap - 3 * r;
+        brow[m] = r;
+        const int px = j + s2 * d;                        // ring pixel (left padding d) of output pixel j, tap column s2
+        boff[m] = (unsigned)(px * 128 + ((chunk ^ (px & 7)) << 4));
+    }
+    // per-lane channel quad (4 consecutive channels cq .. cq + 3 of pixel j)
+    const int cq = cw + 4 * g;
+    const bool cq_ok = cq < p.C;                          // C % 8 == 0 and cq % 4 == 0: a quad is valid as a whole ... or not
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4], is[4], msc[4], msh[4];
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool on = cq_ok && p.bnx;
+            mu[e] = on ? p.bn_mean[cq + e] : 0.f;
+            is[e] = on ? p.bn_rstd[cq + e] : 0.f;
+            msc[e] = (on && p.bn_w ? p.bn_w[cq + e] : 1.f) * is[e];
+            msh[e] = fmaf(-mu[e], msc[e], on && p.bn_b ? p.bn_b[cq + e] : 0.f);
+        }
+    }
+    const int nseg = (W + 15) >> 4;
+    bf16_raw* outp = reinterpret_cast<bf16_raw*>(p.out);
+    const long img_px = (long)n * p.H * W;
+
+    stage(ya - d, TS + 2 * d);
+    for (int y0 = ya; y0 < yb; y0 += TS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // this step's rows have landed; everyone is done with the rows about to be replaced
+        if (y0 + TS < yb) stage(y0 + TS + d, TS);
+        const int nrow = min(TS, yb - y0);
+        for (int ry = 0; ry < nrow; ++ry) {
+            const int rb = (y0 - ya) + ry;                 // ring row index (mod NR) of tap row 0
+            const int sl0 = (rb % NR) * rowb, sl1 = ((rb + d) % NR) * rowb, sl2 = ((rb + 2 * d) % NR) * rowb;   // uniform
+            unsigned badr[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) badr[m] = (unsigned)(brow[m] == 0 ? sl0 : (brow[m] == 1 ? sl1 : sl2)) + boff[m];
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int x0 = sg * 16;
+                f32x4w acc = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const i32x4w b = *reinterpret_cast<const i32x4w*>(smem6 + x0 * 128 + badr[m]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[m]),
+                                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+                }
+                const int x = x0 + j;
+                const bool ok = cq_ok && x < W;
+                const long e0 = (img_px + (long)(y0 + ry) * W + x) * p.C + cq;
+                float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+                if (MODE == 0) {
+                    if (ok) {
+                        uint2 o;
+                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(outp + e0) = o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2a[e] = fmaf(v[e], v[e], s2a[e]); }
+                    }
+                } else if (ok) {
+                    if (p.res) {
+                        const uint2 r2 = *reinterpret_cast<const uint2*>(p.res + e0);
+                        v[0] += bf2f((bf16_raw)(r2.x & 0xffffu)); v[1] += bf2f((bf16_raw)(r2.x >> 16));
+                        v[2] += bf2f((bf16_raw)(r2.y & 0xffffu)); v[3] += bf2f((bf16_raw)(r2.y >> 16));
+                    }
+                    if (p.bnx) {
+                        const uint2 x2 = *reinterpret_cast<const uint2*>(p.bnx + e0);
+                        const float xv[4] = {bf2f((bf16_raw)(x2.x & 0xffffu)), bf2f((bf16_raw)(x2.x >> 16)),
+                                             bf2f((bf16_raw)(x2.y & 0xffffu)), bf2f((bf16_raw)(x2.y >> 16))};
+                        float av[4];
+                        if (p.bna) {
+                            const uint2 a2 = *reinterpret_cast<const uint2*>(p.bna + e0);
+                            av[0] = bf2f((bf16_raw)(a2.x & 0xffffu)); av[1] = bf2f((bf16_raw)(a2.x >> 16));
+                            av[2] = bf2f((bf16_raw)(a2.y & 0xffffu)); av[3] = bf2f((bf16_raw)(a2.y >> 16));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) av[e] = fmaf(xv[e], msc[e], msh[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = av[e] > 0.f ? v[e] : 0.f;
+                        uint2 o;
+                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(outp + e0) = o;
+                        // reduce exactly what BN backward will read back (bf16-rounded)
+                        const float rv[4] = {bf2f((bf16_raw)(o.x & 0xffffu)), bf2f((bf16_raw)(o.x >> 16)),
+                                             bf2f((bf16_raw)(o.y & 0xffffu)), bf2f((bf16_raw)(o.y >> 16))};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[e] += rv[e]; s2a[e] = fmaf(rv[e], (xv[e] - mu[e]) * is[e], s2a[e]); }
+                    } else {
+                        uint2 o;
+                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(outp + e0) = o;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {                                         // uniform
+        // fold the 16 pixel lanes of a row (DPP), one atomic pair per channel and wave
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] = dw_row16_sum(s1[e]); s2a[e] = dw_row16_sum(s2a[e]); }
+        if (j == 0 && cq_ok) {
+            float* dst = p.stats + (long)(bxi % p.stat_reps) * 2 * p.C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(dst + cq + e, s1[e]);
+                atomicAdd(dst + p.C + cq + e, s2a[e]);
+            }
+        }
+    }
+}
+
+template <int MODE>
+inline int launch_dw6(const void* in, const void* w9, void* out, int N, int C, int H, int W, int dil, int flip,
+                      hipStream_t st, float* stats = nullptr, int stat_reps = 1, Dw4Bn bn = Dw4Bn{}) {
+    const long in_bytes = (long)N * H * W * C * 2;
+    if (in_bytes >= (1L << 31) - (1L << 24) || W < 8) return -2;
+    const int rowpx = (W + 2 * dil + 7) / 8 * 8;
+    const long row_bytes = (long)rowpx * 128;
+    // the last 16-pixel segment of a row may read past the row's end — into the next ring slot, or, from the last
+    // slot, into this guard band; what it reads there only reaches output pixels >= W, which are not stored
+    const long guard = (long)(16 + 2 * dil) * 128;
+    int TS = 4 < H ? 4 : H;                             // two resident blocks per CU when a ring fits in 80 KiB
+    while (TS >= 1 && (2 * TS + 2 * dil) * row_bytes + guard > 80 * 1024) --TS;
+    if (TS < 1) return -2;                              // generation 4 takes the wide maps (one block per CU)
+    const int NR = 2 * TS + 2 * dil;
+    const long lds = NR * row_bytes + guard;
+    const long slabs = (C + 63) / 64, slots = 256L * 2;
+    int best_hs = 1;
+    long best_cost = -1;
+    for (int hs = 1; hs <= 4; ++hs) {
+        const int rows = (H + hs - 1) / hs;
+        if (hs > 1 && rows < 2 * TS) break;
+        const long bands = (H + rows - 1) / rows;
+        const long rounds = (N * slabs * bands + slots - 1) / slots;
+        const long cost = rounds * (rows + 2 * dil);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_hs = hs; }
+    }
+    const int rows_split = (H + best_hs - 1) / best_hs;
+    const int hsplit = (H + rows_split - 1) / rows_split;
+    const long nb = (long)N * hsplit;
+    if (nb > 0x7fffffffL) return -4;
+    Dw4 p{(const bf16_raw*)in, nullptr, (const bf16_raw*)w9, out, N, C, H, W, dil, TS, NR, hsplit, rows_split,
+          flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps,
+          (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd, bn.w, bn.b};
+    auto kfn = dwconv6_kernel<MODE>;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); once = true; }
+    if (nb * slabs > 0x7fffffffL) return -4;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(nb * slabs)), dim3(256), (size_t)lds, st, p);
+    return DP_LAUNCH_STATUS();
+}
+
 // 4 = rolling row window (default); 5 = as 4, with the weight gradient on the matrix cores (opt-in: measured
 // slower, see dwconv5_wgrad_kernel); 3 = LDS row tiles, 2 / 1 = the strip / flat mappings
 static int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 4;
@@ -1076,7 +1334,7 @@ static int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")
 // tests / tools: select the kernel generation at run time (returns the previous one)
 DP_EXPORT int dp_dwconv_set_gen(int gen) {
     const int old = kDwGen;
-    if (gen >= 1 && gen <= 5) kDwGen = gen;
+    if (gen >= 1 && gen <= 7) kDwGen = gen;
     return old;
 }
 
@@ -1084,6 +1342,10 @@ DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C
                             int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
+        if (kDwGen >= 6) {
+            const int rc = launch_dw6<0>(x, w9, y, N, C, Hi, Wi, dil, 0, st);
+            if (rc != -2) return rc;
+        }
         if (kDwGen >= 4) {
             const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st);
             if (rc != -2) return rc;
@@ -1115,7 +1377,11 @@ DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N
                                  int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
-        if (kDwGen >= 4) {                                           // = forward over dy with the taps flipped
+        if (kDwGen >= 6) {                                           // = forward over dy with the taps flipped
+            const int rc = launch_dw6<0>(dy, w9, dx, N, C, Hi, Wi, dil, 1, st);
+            if (rc != -2) return rc;
+        }
+        if (kDwGen >= 4) {
             const int rc = launch_dw4<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, st);
             if (rc != -2) return rc;
         }
@@ -1143,7 +1409,7 @@ DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int
                                    int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
     if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
-        if (kDwGen >= 5) {
+        if (kDwGen == 5) {
             const int rc = launch_dw5w(x, dy, dw9, N, C, Hi, Wi, dil, st);
             if (rc != -2) return rc;
         }
@@ -1187,6 +1453,10 @@ DP_EXPORT int dp_dwconv_fwd_stats(const void* x, const void* w9, void* y, float*
                                   hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || !stats || stat_reps < 1) return -1;
     if (!(kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi)) return -2;
+    if (kDwGen >= 6) {
+        const int rc = launch_dw6<0>(x, w9, y, N, C, Hi, Wi, dil, 0, st, stats, stat_reps);
+        if (rc != -2) return rc;
+    }
     if (kDwGen >= 4) {
         const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st, stats, stat_reps);
         if (rc != -2) return rc;
@@ -1211,6 +1481,11 @@ DP_EXPORT int dp_dwconv_bwd_data_fused(const void* dy, const void* w9, void* dx,
     if (!bnx && !res) return -1;
     if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)res | (uintptr_t)bna | (uintptr_t)bnx | (uintptr_t)w9) & 15) return -3;
     if (kDwGen < 4) return -2;
+    if (kDwGen >= 7) {
+        const int rc = launch_dw6<1>(dy, w9, dx, N, C, H, W, dil, 1, st, bnx ? sums : nullptr, reps,
+                                     Dw4Bn{res, bna, bnx, bn_mean, bn_rstd, bn_w, bn_b});
+        if (rc != -2) return rc;
+    }
     return launch_dw4<1>(dy, nullptr, w9, dx, N, C, H, W, dil, 1, st, bnx ? sums : nullptr, reps,
                          Dw4Bn{res, bna, bnx, bn_mean, bn_rstd, bn_w, bn_b});
 }

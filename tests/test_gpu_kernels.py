@@ -206,13 +206,25 @@ def test_wgrad_splits(case, splits):
     assert _rel(dw - 1.0, wr.grad) < 1e-2
 
 
+@pytest.fixture
+def dw_gen(request):
+    """Depthwise kernel generation for one test (csrc/depthwise.hip, dp_dwconv_set_gen); restored afterwards."""
+    from distributedpytorch_amd.ops import _hip_conv
+    lib = _hip_conv._lib()
+    old = lib.dp_dwconv_set_gen(request.param)
+    yield request.param
+    lib.dp_dwconv_set_gen(old)
+
+
+@pytest.mark.parametrize("dw_gen", [4, 6], indirect=True)
 @pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
 @pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (1, 64, 7, 129), (1, 64, 9, 200),
                                    (5, 64, 3, 5)])
-def test_depthwise(stride, dil, shape):
+def test_depthwise(stride, dil, shape, dw_gen):
     """flat kernels (stride 2), the rolling-window kernels (stride 1: several bands per image, partial 64-channel
-    slab, one to four rows per step) and the row-tiled kernels behind them (maps wider than 160 columns) against
-    an fp32 CPU grouped convolution."""
+    slab, one to four rows per step; generation 4 = packed dot products, 6 = forward / data gradient on the matrix
+    cores) and the row-tiled kernels behind them (maps wider than 160 columns) against an fp32 CPU grouped
+    convolution."""
     torch.manual_seed(1)
     n, c, h, w = shape
     x = _bf(torch.randn(n, c, h, w, device=DEV))

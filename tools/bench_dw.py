@@ -40,8 +40,11 @@ def timeit(fn, iters=5, inner=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--gen", type=int, default=0, help="depthwise kernel generation (0: the library's default)")
     args = ap.parse_args()
     from distributedpytorch_amd.ops import _hip_conv
+    if args.gen:
+        _hip_conv._lib().dp_dwconv_set_gen(args.gen)
     tot = [0.0, 0.0, 0.0]
     for name, cnt, c, hw, d in SHAPES:
         x = torch.randn(args.batch, c, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
