@@ -585,6 +585,7 @@ struct Dw4 {
     // entered that activation); bn_w / bn_b null = 1 / 0.
     const bf16_raw* res; const bf16_raw* bna; const bf16_raw* bnx; const float* bn_mean; const float* bn_rstd;
     const float* bn_w; const float* bn_b;
+    int wsplit = 1, cols_split = 1 << 30;     // column bands (dwconv4 only: maps wider than 32 * kDw4K columns)
 };
 
 //   MODE 0: out = depthwise conv of `in` (+ BatchNorm statistics of out);  MODE 1: see Dw4::res;
@@ -597,19 +598,32 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bxi, byi;
-    dw_block_coords(p.N * p.hsplit, (p.C + 63) >> 6, p.C, bxi, byi);
+    dw_block_coords(p.N * p.hsplit * p.wsplit, (p.C + 63) >> 6, p.C, bxi, byi);
     const int c0 = byi * 64;
     const int ncg = min(8, (p.C - c0) >> 3);
-    const int n = bxi / p.hsplit, hs = bxi - n * p.hsplit;
+    // bxi = (image, horizontal band hs, column band ws): maps wider than a step's 32 * kDw4K pixels are cut into
+    // column bands of W <= 160 columns (+ d halo columns each side, fetched from the neighbouring band's pixels)
+    const int bands = p.hsplit * p.wsplit;
+    const int n = bxi / bands, hw = bxi - n * bands;
+    const int hs = hw / p.wsplit, ws = hw - hs * p.wsplit;
     const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
-    const int d = p.dil, W = p.W, TS = p.TS, NR = p.NR;
+    const int xa = ws * p.cols_split, Wi = p.W;
+    const int W = min(Wi, xa + p.cols_split) - xa;          // columns of this band
+    const int d = p.dil, TS = p.TS, NR = p.NR;
+    const bool banded = p.wsplit > 1;                       // uniform
+    // global pixel index (row-major in the image) of pixel pi of the step starting at row y0
+    auto gpix = [&](int y0_, int pi) -> long {
+        if (!banded) return (long)y0_ * Wi + pi;
+        const int r = pi / W;
+        return (long)(y0_ + r) * Wi + xa + (pi - r * W);
+    };
     const int cg = tid & 7, pl = tid >> 3;
     const bool cg_ok = cg < ncg;
     const int ipr = p.rowpx >> 3;        // wave-instructions per staged row
     const int rowch = p.rowpx * 8;       // 16-byte chunks per ring row
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
     const int c8 = lane & 7;
-    const unsigned img = (unsigned)(((long)n * p.H * W * p.C + c0 + c8 * 8) * 2);
+    const unsigned img = (unsigned)(((long)n * p.H * Wi * p.C + c0 + c8 * 8) * 2);
 
     // image rows r_first .. r_first + nrows - 1 -> their ring slots (rows outside the image, the horizontal
     // padding and channel groups beyond C get an out-of-range offset: the buffer range check writes zeros)
@@ -618,22 +632,22 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
             const int rr = i / ipr, seg = i - rr * ipr;
             const int iy = r_first + rr;
             const int slot = (iy - (ya - d)) % NR;
-            const int px = seg * 8 + (lane >> 3) - d;
-            const bool ok = (c8 < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)W);
-            const unsigned off = img + (unsigned)((iy * W + px) * p.C * 2);
+            const int px = xa + seg * 8 + (lane >> 3) - d;            // image column (the halo may be a neighbour band's)
+            const bool ok = (c8 < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)Wi);
+            const unsigned off = img + (unsigned)((iy * Wi + px) * p.C * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsrc, (__attribute__((address_space(3))) void*)(smem4 + ((long)slot * rowch + seg * 64) * 16), 16,
                 ok ? off : kOOBd, 0, 0, 0);
         }
     };
-    const bf16_raw* in2 = MODE == 2 ? p.in2 + ((long)n * p.H * W) * p.C + c0 + cg * 8 : nullptr;
+    const bf16_raw* in2 = MODE == 2 ? p.in2 + ((long)n * p.H * Wi) * p.C + c0 + cg * 8 : nullptr;
     auto load_dy = [&](uint4 (&dq)[kDw4K], int y0) {
         const int npix = min(TS, yb - y0) * W;
 #pragma unroll
         for (int k = 0; k < kDw4K; ++k) {
             const int pi = pl + 32 * k;
             dq[k] = make_uint4(0, 0, 0, 0);
-            if (cg_ok && pi < npix) dq[k] = *reinterpret_cast<const uint4*>(in2 + ((long)y0 * W + pi) * p.C);
+            if (cg_ok && pi < npix) dq[k] = *reinterpret_cast<const uint4*>(in2 + gpix(y0, pi) * p.C);
         }
     };
 
@@ -651,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
             const int pi = pl + 32 * k;
             q[k] = make_uint4(0, 0, 0, 0);
             if (cg_ok && pi < npix)
-                q[k] = *reinterpret_cast<const uint4*>(p.bnx + ((long)n * p.H * W + (long)y0 * W + pi) * p.C + c0 + cg * 8);
+                q[k] = *reinterpret_cast<const uint4*>(p.bnx + ((long)n * p.H * Wi + gpix(y0, pi)) * p.C + c0 + cg * 8);
         }
     };
     if (MODE == 1) {
@@ -690,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
         load_dy(dq, ya);
     }
     stage(ya - d, TS + 2 * d);
-    const long img_el = ((long)n * p.H * W) * p.C + c0 + cg * 8;
+    const long img_el = ((long)n * p.H * Wi) * p.C + c0 + cg * 8;
     bf16_raw* outp = MODE <= 1 ? reinterpret_cast<bf16_raw*>(p.out) + img_el : nullptr;
 
     for (int y0 = ya; y0 < yb; y0 += TS) {
@@ -712,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                 if (pi < npix) {
                     uint4 ga = make_uint4(0, 0, 0, 0), gr = ga;      // MODE 1: issued ahead of the tap reads
                     if (MODE == 1 && cg_ok) {
-                        const long go = img_el + ((long)y0 * W + pi) * p.C;
+                        const long go = img_el + gpix(y0, pi) * p.C;
                         if (p.bna) ga = *reinterpret_cast<const uint4*>(p.bna + go);
                         if (p.res) gr = *reinterpret_cast<const uint4*>(p.res + go);
                     }
@@ -759,14 +773,14 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                             for (int j = 0; j < 8; ++j) acc[j] = av[j] > 0.f ? acc[j] : 0.f;
                             const uint4 o = pack8(acc);
                             unpack8(o, acc);             // reduce exactly what BN backward will read back
-                            if (cg_ok) *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = o;
+                            if (cg_ok) *reinterpret_cast<uint4*>(outp + gpix(y0, pi) * p.C) = o;
 #pragma unroll
                             for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], (xv[j] - mu[j]) * is[j], s2[j]); }
                         } else if (cg_ok) {
-                            *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = pack8(acc);
+                            *reinterpret_cast<uint4*>(outp + gpix(y0, pi) * p.C) = pack8(acc);
                         }
                     } else {
-                        if (cg_ok) *reinterpret_cast<uint4*>(outp + ((long)y0 * W + pi) * p.C) = pack8(acc);
+                        if (cg_ok) *reinterpret_cast<uint4*>(outp + gpix(y0, pi) * p.C) = pack8(acc);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
                     }
@@ -888,9 +902,11 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
                       int flip, hipStream_t st, float* stats = nullptr, int stat_reps = 1, Dw4Bn bn = Dw4Bn{}) {
     const long in_bytes = (long)N * H * W * C * 2;
     if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
-    const int rowpx = (W + 2 * dil + 7) / 8 * 8;
+    const int wsplit = (W + 32 * kDw4K - 1) / (32 * kDw4K);          // column bands of at most 160 columns
+    const int Wb = (W + wsplit - 1) / wsplit;
+    const int rowpx = (Wb + 2 * dil + 7) / 8 * 8;
     const long row_bytes = (long)rowpx * 128;
-    int ts_max = (32 * kDw4K) / W;
+    int ts_max = (32 * kDw4K) / Wb;
     if (ts_max > 4) ts_max = 4;
     if (ts_max > H) ts_max = H;
     if (ts_max < 1) return -2;
@@ -916,17 +932,19 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
         const int rows = (H + hs - 1) / hs;
         if (hs > 1 && rows < 2 * TS) break;
         const long bands = (H + rows - 1) / rows;
-        const long rounds = (N * slabs * bands + slots - 1) / slots;
+        const long rounds = (N * slabs * bands * wsplit + slots - 1) / slots;
         const long cost = rounds * (rows + 2 * dil);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_hs = hs; }
     }
     const int rows_split = (H + best_hs - 1) / best_hs;
     const int hsplit = (H + rows_split - 1) / rows_split;
-    const long nb = (long)N * hsplit;
+    const long nb = (long)N * hsplit * wsplit;
     if (nb > 0x7fffffffL) return -4;
     Dw4 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TS, NR, hsplit, rows_split,
           flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps,
           (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd, bn.w, bn.b};
+    p.wsplit = wsplit;
+    p.cols_split = Wb;
     auto kfn = dwconv4_kernel<MODE>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
