@@ -187,9 +187,23 @@ WGRAD_CASES = [
 ]
 
 
+@pytest.fixture
+def wgrad_mfma(request):
+    """MFMA shape of the weight-gradient kernel for one test (csrc/conv_wgrad.hip, dp_wgrad_set_mfma)."""
+    from distributedpytorch_amd.ops import _hip_conv
+    lib = _hip_conv._lib()
+    old = lib.dp_wgrad_set_mfma(request.param)
+    yield request.param
+    if old in (16, 32):
+        lib.dp_wgrad_set_mfma(old)
+    else:
+        lib.dp_wgrad_set_mfma(16)
+
+
+@pytest.mark.parametrize("wgrad_mfma", [16, 32], indirect=True)
 @pytest.mark.parametrize("splits", [0, 1, 3, 5])
 @pytest.mark.parametrize("case", WGRAD_CASES)
-def test_wgrad_splits(case, splits):
+def test_wgrad_splits(case, splits, wgrad_mfma):
     """csrc/conv_wgrad.hip: forced split-K counts (tail splits, one split) against an fp32 CPU
     weight gradient; also accumulation into a pre-filled gradient buffer."""
     from distributedpytorch_amd.ops import _hip_conv

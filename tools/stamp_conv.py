@@ -25,8 +25,8 @@ def build(lib_path, defs):
     b.build_all()
     objs = []
     for src in b.hip_sources():
-        if os.path.basename(src) == "conv_igemm2.hip":
-            obj = lib_path[:-3] + ".conv_igemm2.o"
+        if os.path.basename(src) in ("conv_igemm2.hip", "conv_wgrad.hip"):
+            obj = lib_path[:-3] + "." + os.path.basename(src) + ".o"
             subprocess.check_call([b.HIPCC, *b.HIP_FLAGS, "-DDP_STAMP=1", *[f"-D{d}" for d in defs], "-c", src, "-o", obj])
         else:
             obj = os.path.join(b.OBJ_DIR, os.path.basename(src) + ".o")
@@ -34,6 +34,52 @@ def build(lib_path, defs):
     objs.append(os.path.join(b.OBJ_DIR, "_build_stamp.o"))
     subprocess.check_call([b.HIPCC, "-shared", "-fPIC", f"--offload-arch={b.ARCH}", "-o", lib_path, *objs])
     print("built", lib_path)
+
+
+def wgrad_main(a, lib, dbg, _hip_conv, torch):
+    """phases of a weight-gradient block: setup | fill | K loop (pixel steps) | - | atomics issued | atomics drained"""
+    lib.dp_wgrad_set_dbg.argtypes = [ctypes.c_void_p]
+    names = ["setup", "fill", "kloop", "-", "atomics", "drain"]
+    print(f"{'shape':20s} {'blocks':>7s} {'steps':>6s} {'us':>8s} {'TF':>6s} | " + " ".join(f"{n:>7s}" for n in names)
+          + " |   total  (us per block, mean over blocks; clock GHz)")
+    for sh in a.shapes:
+        f = [int(v) for v in sh.split(":")]
+        cin, cout, hw, k = f[:4]
+        dil = f[4] if len(f) > 4 else 1
+        pad = dil * (k - 1) // 2
+        n = a.batch
+        cl = torch.channels_last
+        x = torch.randn(n, cin, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=cl)
+        dy = torch.randn(n, cout, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=cl)
+        dw = torch.zeros(cout, cin, k, k, device="cuda").contiguous(memory_format=cl)
+        gf = 2.0 * n * hw * hw * cin * cout * k * k / 1e9
+
+        def run():
+            _hip_conv.wgrad(dy, x, (cout, cin, k, k), (1, 1), (pad, pad), (dil, dil), out=dw)
+        lib.dp_wgrad_set_dbg(None)
+        for _ in range(3):
+            run()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        t_us = sorted(ts)[2]
+        dbg.zero_()
+        lib.dp_wgrad_set_dbg(ctypes.c_void_p(dbg.data_ptr()))
+        run()
+        torch.cuda.synchronize()
+        lib.dp_wgrad_set_dbg(None)
+        d = dbg.view(-1, 16).cpu()
+        d = d[d[:, 0] != 0].double()
+        if d.numel() == 0:
+            print(f"{sh:20s} (no stamps: first-generation kernel)")
+            continue
+        ghz = float(((d[:, 6] - d[:, 0]) / (d[:, 8] - d[:, 7]).clamp(min=1)).median()) * 0.1
+        ph = (d[:, 1:7] - d[:, 0:6]).mean(0) / (ghz * 1e3)
+        tot = float((d[:, 6] - d[:, 0]).mean() / (ghz * 1e3))
+        print(f"{sh:20s} {d.shape[0]:7d} {float(d[:, 11].mean()):6.1f} {t_us:8.1f} {gf / t_us * 1e3:6.0f} | "
+              + " ".join(f"{float(v):7.2f}" for v in ph) + f" | {tot:7.2f}  ({ghz:.2f})", flush=True)
 
 
 def main():
@@ -44,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--cfgs", default="5")
     ap.add_argument("--modes", default="plain,stats,res,resaff,bn")
+    ap.add_argument("--wgrad", action="store_true", help="stamp the weight-gradient kernel instead (csrc/conv_wgrad.hip)")
     ap.add_argument("--stagger", default="0,0", help="';'-separated 'slot,cu' start-time staggers (units of 1024 cycles)")
     ap.add_argument("shapes", nargs="*", help="cin:cout:hw:k[:dil]")
     a = ap.parse_args()
@@ -58,6 +105,8 @@ def main():
     lib.dp_conv_set_stagger.argtypes = [ctypes.c_int, ctypes.c_int]
     staggers = [tuple(int(v) for v in st.split(",")) for st in a.stagger.split(";")]
     dbg = torch.zeros(16 * (1 << 19), dtype=torch.int64, device="cuda")
+    if a.wgrad:
+        return wgrad_main(a, lib, dbg, _hip_conv, torch)
     names = ["setup", "fill", "kloop", "stageC", "store", "drain"]
     print(f"{'shape':20s} {'mode':7s} cfg {'blocks':>7s} {'us':>8s} {'TF':>6s} | " + " ".join(f"{n:>7s}" for n in names)
           + " |   total  (us per block, mean over blocks; clock GHz; blocks of a CU inside their K loops at once)")
