@@ -294,9 +294,18 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
 #pragma unroll
     for (int t = 0; t < kD / 16; ++t) dkacc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+    // lse / delta' of the block's 32 queries travel with the prefetch as well (8 of each per lane): read inside the
+    // step under their bounds tests they were 16 dependent global loads with a wait each — 4 of a step's 6 us
     uint4 yreg[8], qreg;
+    float lnext[8], dnext[8];
     auto fetch = [&](int qb) {
         const int qrow0 = qb * kBQB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int qg = min(qrow0 + (i >> 2) * 16 + 4 * g + (i & 3), p.N - 1);
+            lnext[i] = p.lse[img + qg];
+            dnext[i] = p.delta[img + qg];
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = tid + i * 256, row = c >> 6, ch = c & 63;
@@ -323,6 +332,9 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
     for (int qb = 0; qb < nqb; ++qb) {
         __syncthreads();                         // the previous step's reads of Ys / Qs / Ss are done
         commit();
+        float lcur[8], dcur[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lcur[i] = lnext[i]; dcur[i] = dnext[i]; }
         __syncthreads();
         if (qb + 1 < nqb) fetch(qb + 1);
         const int qrow0 = qb * kBQB;
@@ -338,13 +350,32 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
                 const bf16x8 qfr = frag16(Qs + (qt * 16 + l15) * kKLD + (ks * 32 + g * 8) * 2);
                 sv[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[ks], sv[qt], 0, 0, 0);
             }
-#pragma unroll 4
-        for (int ks = 0; ks < kDVB / 32; ++ks) {
-            const bf16x8 vfr = frag16(Vs + (wave * 16 + l15) * kWLD + (ks * 32 + g * 8) * 2);
+        {
+            // fragments of the NEXT pair of k-steps are requested before the MFMAs of the current pair (left alone
+            // hipcc reads, waits lgkmcnt(0) and multiplies one k-step at a time: an LDS round trip per MFMA with one
+            // wave per SIMD)
+            constexpr int KS = kDVB / 32, GP = 2;
+            bf16x8 vf[2][GP], yf[2][GP][2];
+            auto rd = [&](int set, int ks0) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const bf16x8 yfr = frag16(Ys + (qt * 16 + l15) * kWLD + (ks * 32 + g * 8) * 2);
-                tv[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yfr, vfr, tv[qt], 0, 0, 0);
+                for (int u = 0; u < GP; ++u) {
+                    vf[set][u] = frag16(Vs + (wave * 16 + l15) * kWLD + ((ks0 + u) * 32 + g * 8) * 2);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        yf[set][u][qt] = frag16(Ys + (qt * 16 + l15) * kWLD + ((ks0 + u) * 32 + g * 8) * 2);
+                }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int kg = 0; kg < KS / GP; ++kg) {
+                if (kg + 1 < KS / GP) rd((kg + 1) & 1, (kg + 1) * GP);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < GP; ++u)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        tv[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[kg & 1][u][qt], vf[kg & 1][u], tv[qt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- P = exp(S - lse), dS = gamma P (T - delta') ----
@@ -354,22 +385,35 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qg = qrow0 + qt * 16 + 4 * g + r;
-                float pe = 0.f, de = 0.f;
-                if (qg < p.N && key_ok) {
-                    pe = __expf(sv[qt][r] - p.lse[img + qg]);
-                    de = gam * pe * (tv[qt][r] - p.delta[img + qg]);
-                }
+                const bool on = qg < p.N && key_ok;
+                const float pe = on ? __expf(sv[qt][r] - lcur[qt * 4 + r]) : 0.f;
                 pv[qt][r] = pe;
-                dsv[qt][r] = de;
+                dsv[qt][r] = on ? gam * pe * (tv[qt][r] - dcur[qt * 4 + r]) : 0.f;
             }
         const bf16x8 pfr = pack_frag(pv[0], pv[1]);          // A[row = key l15][k = query (g, j)]
         const bf16x8 dsfr = pack_frag(dsv[0], dsv[1]);
         // ---- dV[key][dv] += P^T dy : B = dy through transposing reads (queries in the same permuted order) ----
         const unsigned char* ybase = Ys + (4 * g + qsel) * kWLD + pp * 8;
+        {
+            constexpr int NT = kDVB / 16, GT = 4;               // 4 value tiles (8 transposed reads) ahead
+            bf16x8 yt[2][GT];
 #pragma unroll
-        for (int t = 0; t < kDVB / 16; ++t) {
-            const bf16x8 yfr = tr_frag2(ybase + t * 32, ybase + 16 * kWLD + t * 32);
-            dvacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr, yfr, dvacc[t], 0, 0, 0);
+            for (int u = 0; u < GT; ++u) yt[0][u] = tr_frag2(ybase + u * 32, ybase + 16 * kWLD + u * 32);
+#pragma unroll
+            for (int tg = 0; tg < NT / GT; ++tg) {
+                if (tg + 1 < NT / GT) {
+#pragma unroll
+                    for (int u = 0; u < GT; ++u) {
+                        const int t = (tg + 1) * GT + u;
+                        yt[(tg + 1) & 1][u] = tr_frag2(ybase + t * 32, ybase + 16 * kWLD + t * 32);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < GT; ++u)
+                    dvacc[tg * GT + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr, yt[tg & 1][u], dvacc[tg * GT + u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- dK[key][d] += dS^T Q ----
         const unsigned char* qbase = Qs + (4 * g + qsel) * kKLD + pp * 8;
