@@ -238,6 +238,9 @@ def main():
                      "exposed_comm_ms": round(comm_wait, 3)},
             "runtime": {"ops_backend": ops.get_backend()},
         }
+        mid = getattr(getattr(model, "backbone", None), "mid_physical", None)
+        if mid is not None:     # Xception-65: the 728-channel flow stored 768 wide (zero padding channels, same network)
+            rec["config"]["mid_channels"] = {"logical": 728, "stored": mid}
         if on_gpu and args.impl == "native":
             from distributedpytorch_amd.ops import _backend, _hip_conv
             bi = _backend.build_info()

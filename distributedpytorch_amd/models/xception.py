@@ -5,10 +5,22 @@ Every separable unit is ``depthwise 3×3 (atrous) → BN → pointwise 1×1 → 
 runs the memory-bound K13 kernel, the pointwise part the MFMA implicit-GEMM kernel (SURVEY.md
 §2.5).  Activations between units are fused into the preceding BN (``relu=True``) wherever the
 pre-activation structure allows it.
+
+**Physical width of the 728-channel flow.**  728 channels are 1456-byte pixel rows: rows straddle the 128-byte
+cache lines, the 64-channel slabs of the depthwise kernels share a line at every seam, and the matrix-core
+kernels round 728 up to 768 anyway (3 tiles of 256 outputs, 12 K-steps of 64).  On the HIP backend the flow is
+therefore STORED 768 wide (``DPAMD_X65_PAD``, `mid_channels(...)`): the 40 extra channels have zero weights, so
+they carry exact zeros forward (conv of zero weights, BN of an all-zero channel, ReLU, shortcut add of two zeros)
+and receive exact zeros backward (every gradient into them is a product with one of those zeros; weight decay
+and momentum of zero stay zero) — the network is the 728-channel network at every step, with aligned rows.
+``state_dict()`` / ``load_state_dict()`` speak the logical 728-channel shapes (hooks below), so checkpoints
+stay loadable by the reference's model code.  Measured: 225.3 → 213.4 ms per step at B64, output stride 8
+(`profiles/r2_x65_mid768_vs_728.log`).
 """
 from __future__ import annotations
 
-from typing import Tuple
+import os
+from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -112,10 +124,40 @@ class XceptionBlock(nn.Module):
         return units[-1](x, residual=short, relu=self.activate_output, sole_consumer=True)
 
 
+MID_CHANNELS = 728                      # the published architecture's middle-flow width
+_PADDED = ("block3.", "middle.", "block20.")   # sub-modules that hold a 728-wide dimension
+
+
+def mid_channels(pad: Optional[bool] = None) -> int:
+    """Physical width of the 728-channel flow: 768 (whole cache lines per pixel row, whole 64-channel slabs) when
+    padding is on.  ``pad=None``: ``DPAMD_X65_PAD`` (``1``/``0``), default: on where the HIP kernels run (a GPU is present and the backend is not 'torch')."""
+    if pad is None:
+        env = os.environ.get("DPAMD_X65_PAD", "auto")
+        if env == "auto":
+            from .. import ops
+            pad = ops.get_backend() != "torch" and torch.cuda.is_available()
+        else:
+            pad = env not in ("0", "off", "false")
+    return 768 if pad else MID_CHANNELS
+
+
+def _logical_state_dict(module, state_dict, prefix, local_metadata):
+    """state_dict hook: the stored 768-wide tensors → the architecture's 728-wide ones (views)."""
+    for key in list(state_dict.keys()):
+        if not (key.startswith(prefix) and key[len(prefix):].startswith(_PADDED)):
+            continue
+        t = state_dict[key]
+        for d in range(min(t.dim(), 2)):
+            if t.shape[d] == module.mid_physical:
+                t = t.narrow(d, 0, MID_CHANNELS)
+        state_dict[key] = t
+    return state_dict
+
+
 class AlignedXception(nn.Module):
     """Returns ``(features[2048], low_level[128 @ stride 4])``."""
 
-    def __init__(self, output_stride: int = 16, in_channels: int = 3):
+    def __init__(self, output_stride: int = 16, in_channels: int = 3, pad_mid: Optional[bool] = None):
         super().__init__()
         if output_stride == 16:
             entry3_stride, mid_dil, exit_dil = 2, 1, (1, 2)
@@ -129,9 +171,10 @@ class AlignedXception(nn.Module):
         self.bn2 = BatchNorm2d(64)
         self.block1 = XceptionBlock(64, 128, 2, stride=2, start_with_relu=False)
         self.block2 = XceptionBlock(128, 256, 2, stride=2, start_with_relu=False)
-        self.block3 = XceptionBlock(256, 728, 2, stride=entry3_stride, is_last=True)
-        self.middle = nn.Sequential(*[XceptionBlock(728, 728, 3, dilation=mid_dil) for _ in range(16)])
-        self.block20 = XceptionBlock(728, 1024, 2, dilation=exit_dil[0], grow_first=False, is_last=True)
+        mid = self.mid_physical = mid_channels(pad_mid)
+        self.block3 = XceptionBlock(256, mid, 2, stride=entry3_stride, is_last=True)
+        self.middle = nn.Sequential(*[XceptionBlock(mid, mid, 3, dilation=mid_dil) for _ in range(16)])
+        self.block20 = XceptionBlock(mid, 1024, 2, dilation=exit_dil[0], grow_first=False, is_last=True)
         self.conv3 = SeparableConv2d(1024, 1536, dilation=exit_dil[1])
         self.bn3 = BatchNorm2d(1536)
         self.conv4 = SeparableConv2d(1536, 1536, dilation=exit_dil[1])
@@ -151,6 +194,56 @@ class AlignedXception(nn.Module):
         # have exactly one consumer
         for blk in chain:
             blk.input_sole = blk is not self.block2
+        if mid != MID_CHANNELS:
+            self.zero_pad_channels()
+            self._register_state_dict_hook(_logical_state_dict)
+            self._register_load_state_dict_pre_hook(self._physical_state_dict)
+
+    # ---- physical 768-wide storage of the 728-channel flow (module docstring) ----
+    def _padded_tensors(self):
+        """(name, tensor, dims that are `mid_physical` wide) of every parameter / buffer that has such a dim."""
+        for name, t in list(self.named_parameters()) + list(self.named_buffers()):
+            if name.startswith(_PADDED):
+                dims = [d for d in range(min(t.dim(), 2)) if t.shape[d] == self.mid_physical]
+                if dims:
+                    yield name, t, dims
+
+    @torch.no_grad()
+    def zero_pad_channels(self) -> None:
+        """Zero every convolution weight that touches a padding channel (after ANY re-initialisation of the
+        weights): that is what makes the padding channels exact zeros in both directions."""
+        for name, t, dims in self._padded_tensors():
+            if t.dim() == 4 or name.endswith(".bias"):      # conv weights; BatchNorm shifts (0 at init anyway)
+                for d in dims:
+                    t.narrow(d, MID_CHANNELS, self.mid_physical - MID_CHANNELS).zero_()
+
+    def logical_num_parameters(self) -> int:
+        n = sum(p.numel() for p in self.parameters())
+        for name, t, dims in self._padded_tensors():
+            if isinstance(t, nn.Parameter):
+                logical = 1
+                for d in range(t.dim()):
+                    logical *= MID_CHANNELS if d in dims else t.shape[d]
+                n -= t.numel() - logical
+        return n
+
+    def _physical_state_dict(self, state_dict, prefix, local_metadata, strict, missing, unexpected, errors):
+        """load_state_dict pre-hook: 728-wide tensors of a checkpoint → the stored width (weights / shifts /
+        running means padded with 0, BatchNorm scales and running variances with 1)."""
+        extra = self.mid_physical - MID_CHANNELS
+        for key in list(state_dict.keys()):
+            if not (key.startswith(prefix) and key[len(prefix):].startswith(_PADDED)):
+                continue
+            t = state_dict[key]
+            for d in range(min(t.dim(), 2)):
+                if t.shape[d] == MID_CHANNELS:
+                    shape = list(t.shape)
+                    shape[d] = extra
+                    one = t.dim() == 1 and (key.endswith("running_var") or key.endswith(".weight"))
+                    fill = torch.ones(shape, dtype=t.dtype, device=t.device) if one \
+                        else torch.zeros(shape, dtype=t.dtype, device=t.device)
+                    t = torch.cat([t, fill], dim=d)
+            state_dict[key] = t
 
     def forward(self, x):
         x = conv_bn_act(self.conv1, self.bn1, x, relu=True)

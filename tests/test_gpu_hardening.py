@@ -195,6 +195,8 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
         for k, p in m_cpu.named_parameters():
             if k.endswith("bn3.weight") or (".rep." in k and k.endswith(".bn.weight") and not k.endswith("sep.bn.weight")):
                 p.mul_(0.15)
+    if hasattr(getattr(m_cpu, "backbone", None), "zero_pad_channels"):
+        m_cpu.backbone.zero_pad_channels()      # Xception's padding channels: zero again after the re-initialisation
     for m in m_cpu.modules():            # dropout off: the fused counter-based generator is not torch's
         if isinstance(getattr(m, "p_drop", None), tuple):
             m.p_drop = (0.0, 0.0)
@@ -240,3 +242,46 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
     # in a fused path lands far below both (0.04-0.4).
     assert last_f > 0.995 and med_f > 0.65, (last_f, med_f)
     assert med_f > med_p - 0.15, (med_f, med_p)
+
+
+def test_xception_padded_flow_stays_the_728_channel_network(tmp_path):
+    """Aligned Xception-65 stores its 728-channel flow 768 wide on the HIP backend (models/xception.py): after real
+    optimizer steps on the kernels (momentum, weight decay, fused BN folds, atomics) the padding weights are still
+    exact zeros, and the checkpoint has the architecture's shapes and loads into an unpadded model."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.models.xception import MID_CHANNELS
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine
+    from distributedpytorch_amd.utils import checkpoint
+    torch.manual_seed(0)
+    net = build_model("deeplabv3plus_xception65", 21, output_stride=8)
+    bb = net.backbone
+    assert bb.mid_physical == 768, "padding is the default on the HIP backend"
+    eng = TrainEngine(net, SoftmaxCrossEntropy(255), lr=0.01, momentum=0.9, weight_decay=5e-4,
+                      device=torch.device("cuda", 0))
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        x = torch.randn(4, 3, 129, 129, generator=g)
+        lab = torch.randint(0, 21, (4, 129, 129), generator=g)
+        loss = eng.train_step(x.cuda(), lab.cuda())
+    assert torch.isfinite(loss).item()
+    n = 0
+    for name, t, dims in bb._padded_tensors():
+        if t.dim() == 4 or name.endswith(".bias"):
+            for d in dims:
+                assert float(t.detach().narrow(d, MID_CHANNELS, 40).float().abs().max()) == 0.0, name
+                n += 1
+    assert n > 150
+    path = str(tmp_path / "x65.pth")
+    checkpoint.save_checkpoint(path, eng.model, sync=False)
+    sd = torch.load(path, weights_only=True)
+    assert sd["module.backbone.middle.0.rep.0.sep.pointwise.weight"].shape == (728, 728, 1, 1)
+    assert sd["module.backbone.block20.skip.weight"].shape == (1024, 728, 1, 1)
+    os.environ["DPAMD_X65_PAD"] = "0"
+    try:
+        plain = build_model("deeplabv3plus_xception65", 21, output_stride=8)
+    finally:
+        del os.environ["DPAMD_X65_PAD"]
+    assert plain.backbone.mid_physical == 728
+    res = checkpoint.load_weights(path, plain)
+    assert not res.missing_keys and not res.unexpected_keys

@@ -382,7 +382,11 @@ def main(argv=None):
     net = build_model(args.model, nclass, output_stride=args.output_stride, sync_bn=args.sync_bn,
                       freeze_bn=args.freeze_bn, in_channels=args.nInputChannels)
     if info.is_master:
-        print("No of parameters: ", sum(p.numel() for p in net.parameters() if p.requires_grad))
+        n_params = sum(p.numel() for p in net.parameters() if p.requires_grad)
+        backbone = getattr(net, "backbone", None)
+        if hasattr(backbone, "logical_num_parameters"):     # Xception's 728-channel flow may be stored 768 wide
+            n_params -= sum(p.numel() for p in backbone.parameters()) - backbone.logical_num_parameters()
+        print("No of parameters: ", n_params)
     criterion = SegmentationMultiLosses(nclass) if instance else ops.SoftmaxCrossEntropy(255)
     engine = TrainEngine(net, criterion, lr=args.lr, momentum=args.momentum, weight_decay=args.wd,
                          head_lr_mult=args.head_lr_mult, device=info.device, bucket_mb=args.bucket_mb,
