@@ -558,6 +558,43 @@ inline int launch_dw3(const void* in, const void* in2, const void* w9, void* out
 // of the current step while LDS-DMA brings the next TS rows in, so every element is fetched once (plus 2d rows
 // per band) and the fetch overlaps the arithmetic.  Ring rows are rowpx = ceil8(W + 2d) pixels wide so one
 // wave-instruction (8 pixels x 128 B) never crosses into the next ring slot.
+// LDS reads of the rolling-window kernels go through inline asm with hand-placed s_waitcnt: hipcc guards every C++
+// LDS load behind `s_waitcnt vmcnt(0)` while an LDS-DMA is pending (it cannot tell the slots apart), which made each
+// pixel group wait for the NEXT step's rows it had just requested and for the previous pixel's global store.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4d;
+__device__ __forceinline__ void dw_lds_rd16(u32x4d& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+// the listed registers are valid once at most N LDS reads are outstanding (reads return in order)
+template <int N>
+__device__ __forceinline__ void dw_lds_wait(u32x4d& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void dw_lds_wait(u32x4d& a, u32x4d& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dw_lds_wait(u32x4d& a, u32x4d& b, u32x4d& c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dw_lds_wait(u32x4d& a, u32x4d& b, u32x4d& c, u32x4d& d, u32x4d& e, u32x4d& f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned wsel(const u32x4d& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+// at most n (wave-uniform, 0..5) vector-memory operations stay outstanding: the youngest n, i.e. this wave's own
+// global stores of the step behind it, not the LDS-DMA issued before them
+__device__ __forceinline__ void dw_wait_vm_keep(int n) {
+    // the builtin, not inline asm: hipcc's own wait-count bookkeeping sees it (with an opaque asm wait it assumed every
+    // load of the previous loop iteration still pending and guarded each register reuse with vmcnt(0)).
+    // gfx9 encoding: vmcnt = bits 3:0 (+15:14), expcnt 6:4 and lgkmcnt 11:8 left at their maxima
+    if (n >= 5) __builtin_amdgcn_s_waitcnt(0x0F75);
+    else if (n == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+    else if (n == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
+    else if (n == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+    else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 constexpr int kDw4K = 5;                // pixels per thread and step: TS * W <= 32 * kDw4K
 
 // The arithmetic is packed bf16 dot products (v_dot2c_f32_bf16: two bf16 products added to an fp32 accumulator)
@@ -624,6 +661,29 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
     const int c8 = lane & 7;
     const unsigned img = (unsigned)(((long)n * p.H * Wi * p.C + c0 + c8 * 8) * 2);
+    // Every other tensor of the kernel (dy, output, shortcut gradient, BatchNorm activation / input) has the input's
+    // shape: per-pixel accesses go through buffer descriptors with an out-of-range offset for lanes without a pixel
+    // (loads return zeros, stores are dropped) and a ZERO-SIZED descriptor for an operand that is not there — the
+    // pixel loop has no branch around a memory instruction, so hipcc counts the outstanding operations exactly and
+    // its s_waitcnt vmcnt(N) never has to assume the worst path.
+    auto mkrs = [&](const void* ptr) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, ptr ? (int)p.in_bytes : 0, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_in2 = mkrs(MODE == 2 ? (const void*)p.in2 : nullptr);
+    const __amdgpu_buffer_rsrc_t rs_out = mkrs(MODE <= 1 ? (const void*)p.out : nullptr);
+    const __amdgpu_buffer_rsrc_t rs_res = mkrs(MODE == 1 ? (const void*)p.res : nullptr);
+    const __amdgpu_buffer_rsrc_t rs_bna = mkrs(MODE == 1 ? (const void*)p.bna : nullptr);
+    const __amdgpu_buffer_rsrc_t rs_bnx = mkrs(MODE == 1 ? (const void*)p.bnx : nullptr);
+    const unsigned el0 = (unsigned)((((long)n * p.H * Wi) * p.C + c0 + (tid & 7) * 8) * 2);
+    const bool cg_in = (tid & 7) < ncg;
+    // byte offset of this thread's 8 channels of pixel pi of the step at row y0_ (out of range: no such pixel)
+    auto goff = [&](int y0_, int pi, int npix_) -> unsigned {
+        return (cg_in && pi < npix_) ? el0 + (unsigned)(gpix(y0_, pi) * p.C * 2) : kOOBd;
+    };
+    auto ldb = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> uint4 {
+        const u32x4d t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+        return make_uint4(t.x, t.y, t.z, t.w);
+    };
 
     // image rows r_first .. r_first + nrows - 1 -> their ring slots (rows outside the image, the horizontal
     // padding and channel groups beyond C get an out-of-range offset: the buffer range check writes zeros)
@@ -640,15 +700,10 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                 ok ? off : kOOBd, 0, 0, 0);
         }
     };
-    const bf16_raw* in2 = MODE == 2 ? p.in2 + ((long)n * p.H * Wi) * p.C + c0 + cg * 8 : nullptr;
     auto load_dy = [&](uint4 (&dq)[kDw4K], int y0) {
         const int npix = min(TS, yb - y0) * W;
 #pragma unroll
-        for (int k = 0; k < kDw4K; ++k) {
-            const int pi = pl + 32 * k;
-            dq[k] = make_uint4(0, 0, 0, 0);
-            if (cg_ok && pi < npix) dq[k] = *reinterpret_cast<const uint4*>(in2 + gpix(y0, pi) * p.C);
-        }
+        for (int k = 0; k < kDw4K; ++k) dq[k] = ldb(rs_in2, goff(y0, pl + 32 * k, npix));
     };
 
     // MODE 0: tap weights as packed pairs — wp[tp][c] = (w[2 tp][c], w[2 tp + 1][c]); the ninth tap pairs with zero
@@ -661,12 +716,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     auto load_bx = [&](uint4 (&q)[MODE == 1 ? kDw4K : 1], int y0) {
         const int npix = min(TS, yb - y0) * W;
 #pragma unroll
-        for (int k = 0; k < (MODE == 1 ? kDw4K : 1); ++k) {
-            const int pi = pl + 32 * k;
-            q[k] = make_uint4(0, 0, 0, 0);
-            if (cg_ok && pi < npix)
-                q[k] = *reinterpret_cast<const uint4*>(p.bnx + ((long)n * p.H * Wi + gpix(y0, pi)) * p.C + c0 + cg * 8);
-        }
+        for (int k = 0; k < (MODE == 1 ? kDw4K : 1); ++k) q[k] = ldb(rs_bnx, goff(y0, pl + 32 * k, npix));
     };
     if (MODE == 1) {
 #pragma unroll
@@ -677,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
             msc[j] = (on && p.bn_w ? p.bn_w[c0 + cg * 8 + j] : 1.f) * is[j];
             msh[j] = fmaf(-mu[j], msc[j], on && p.bn_b ? p.bn_b[c0 + cg * 8 + j] : 0.f);
         }
-        if (p.bnx) load_bx(bx, ya);
+        load_bx(bx, ya);          // (a zero-sized descriptor when there is no BatchNorm prologue)
     }
     if (MODE <= 1) {
         uint4 wr[9];
@@ -707,54 +757,86 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
     const long img_el = ((long)n * p.H * Wi) * p.C + c0 + cg * 8;
     bf16_raw* outp = MODE <= 1 ? reinterpret_cast<bf16_raw*>(p.out) + img_el : nullptr;
 
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem4;
+    const unsigned qd = (unsigned)d * 128u;          // bytes between the taps of a filter row
+    int kept = 0;                                    // global stores this wave issued in the step behind it (uniform)
     for (int y0 = ya; y0 < yb; y0 += TS) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the rows requested a step ago have landed; the stores issued after them may still be in flight
+        dw_wait_vm_keep(MODE <= 1 ? kept : 0);
         __syncthreads();          // this step's rows have landed; everyone is done with the rows about to be replaced
         const bool more = y0 + TS < yb;
         if (more) {
             stage(y0 + TS + d, TS);
             if (MODE == 2) load_dy(dqn, y0 + TS);
-            if (MODE == 1 && p.bnx) load_bx(bxn, y0 + TS);
+            if (MODE == 1) load_bx(bxn, y0 + TS);
         }
         const int npix = min(TS, yb - y0) * W;
         const int rbase = (y0 - ya) % NR;
         int ry = pl / W, x = pl - ry * W;
         if (MODE <= 1) {
+            // stores of this step, as the next step's wait counts them (every wave issues all of them: lanes
+            // without a pixel store to an out-of-range offset)
+            kept = kDw4K;
+            // MODE 1: the mask / shortcut operands of pixel k + 1 are requested before pixel k is stored, so waiting
+            // for them never waits for that store (the counter retires in issue order); two buffers by the parity
+            // of k, so that no register is reused while a load into it is in flight
+            uint4 gaq[2], grq[2];
+            unsigned go_n = goff(y0, pl, npix);
+            if (MODE == 1) { gaq[0] = ldb(rs_bna, go_n); grq[0] = ldb(rs_res, go_n); }
 #pragma unroll
             for (int k = 0; k < kDw4K; ++k) {
                 const int pi = pl + 32 * k;
-                if (pi < npix) {
-                    uint4 ga = make_uint4(0, 0, 0, 0), gr = ga;      // MODE 1: issued ahead of the tap reads
-                    if (MODE == 1 && cg_ok) {
-                        const long go = img_el + gpix(y0, pi) * p.C;
-                        if (p.bna) ga = *reinterpret_cast<const uint4*>(p.bna + go);
-                        if (p.res) gr = *reinterpret_cast<const uint4*>(p.res + go);
-                    }
-                    int r0 = rbase + ry;  r0 -= r0 >= NR ? NR : 0;
+                const bool ok = pi < npix;
+                const unsigned go = go_n;
+                if (k + 1 < kDw4K) {
+                    go_n = goff(y0, pi + 32, npix);
+                    if (MODE == 1) { gaq[(k + 1) & 1] = ldb(rs_bna, go_n); grq[(k + 1) & 1] = ldb(rs_res, go_n); }
+                }
+                const uint4& ga = gaq[k & 1];
+                const uint4& gr = grq[k & 1];
+                {
+                    const int xe = ok ? x : 0, rye = ok ? ry : 0;     // lanes without a pixel recompute pixel 0
+                    int r0 = rbase + rye; r0 -= r0 >= NR ? NR : 0;
                     int r1 = r0 + d;      r1 -= r1 >= NR ? NR : 0;
                     int r2 = r1 + d;      r2 -= r2 >= NR ? NR : 0;
-                    const uint4* t0 = ring + r0 * rowch + x * 8 + cg;
-                    const uint4* t1 = ring + r1 * rowch + x * 8 + cg;
-                    const uint4* t2 = ring + r2 * rowch + x * 8 + cg;
-                    uint4 v[9];
+                    const unsigned a0 = lds0 + (unsigned)(r0 * rowch + xe * 8 + cg) * 16u;
+                    const unsigned a1 = lds0 + (unsigned)(r1 * rowch + xe * 8 + cg) * 16u;
+                    const unsigned a2 = lds0 + (unsigned)(r2 * rowch + xe * 8 + cg) * 16u;
+                    u32x4d v[9];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) { v[q] = t0[q * d * 8]; v[3 + q] = t1[q * d * 8]; v[6 + q] = t2[q * d * 8]; }
+                    for (int q = 0; q < 3; ++q) dw_lds_rd16(v[q], a0 + q * qd);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) dw_lds_rd16(v[3 + q], a1 + q * qd);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) dw_lds_rd16(v[6 + q], a2 + q * qd);
                     float acc[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-                    for (int tp = 0; tp < 4; ++tp)
+                    for (int tp = 0; tp < 4; ++tp) {
+                        if (tp == 0) dw_lds_wait<7>(v[0], v[1]);
+                        if (tp == 1) dw_lds_wait<5>(v[2], v[3]);
+                        if (tp == 2) dw_lds_wait<3>(v[4], v[5]);
+                        if (tp == 3) dw_lds_wait<1>(v[6], v[7]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const unsigned a = wsel(v[2 * tp], i), b = wsel(v[2 * tp + 1], i);
                             acc[2 * i] = dot2bf(pair_lo(a, b), wp[tp][2 * i], acc[2 * i]);
                             acc[2 * i + 1] = dot2bf(pair_hi(a, b), wp[tp][2 * i + 1], acc[2 * i + 1]);
                         }
+                    }
+                    dw_lds_wait<0>(v[8]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[2 * i] = dot2bf(wsel(v[8], i), w8[2 * i], acc[2 * i]);
                         acc[2 * i + 1] = dot2bf(wsel(v[8], i), w8[2 * i + 1], acc[2 * i + 1]);
                     }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = ok ? acc[j] : 0.f;      // nothing of a lane without a pixel is summed
+                    auto stb = [&](const uint4& o) {
+                        u32x4d t; t.x = o.x; t.y = o.y; t.z = o.z; t.w = o.w;
+                        __builtin_amdgcn_raw_buffer_store_b128(t, rs_out, (int)go, 0, 0);
+                    };
                     if (MODE == 1) {
                         float rv[8];
                         unpack8(gr, rv);
@@ -773,14 +855,14 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                             for (int j = 0; j < 8; ++j) acc[j] = av[j] > 0.f ? acc[j] : 0.f;
                             const uint4 o = pack8(acc);
                             unpack8(o, acc);             // reduce exactly what BN backward will read back
-                            if (cg_ok) *reinterpret_cast<uint4*>(outp + gpix(y0, pi) * p.C) = o;
+                            stb(o);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], (xv[j] - mu[j]) * is[j], s2[j]); }
-                        } else if (cg_ok) {
-                            *reinterpret_cast<uint4*>(outp + gpix(y0, pi) * p.C) = pack8(acc);
+                        } else {
+                            stb(pack8(acc));
                         }
                     } else {
-                        if (cg_ok) *reinterpret_cast<uint4*>(outp + gpix(y0, pi) * p.C) = pack8(acc);
+                        stb(pack8(acc));
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
                     }
@@ -803,24 +885,40 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                     int a0 = rbase + ryA;  a0 -= a0 >= NR ? NR : 0;
                     int a1 = a0 + d;       a1 -= a1 >= NR ? NR : 0;
                     int a2 = a1 + d;       a2 -= a2 >= NR ? NR : 0;
-                    const uint4* tA[3] = {ring + a0 * rowch + xA * 8 + cg, ring + a1 * rowch + xA * 8 + cg,
-                                          ring + a2 * rowch + xA * 8 + cg};
+                    const unsigned tA[3] = {lds0 + (unsigned)(a0 * rowch + xA * 8 + cg) * 16u,
+                                            lds0 + (unsigned)(a1 * rowch + xA * 8 + cg) * 16u,
+                                            lds0 + (unsigned)(a2 * rowch + xA * 8 + cg) * 16u};
                     const bool pairB = (2 * kp + 1 < kDw4K) && piB < npix;
                     if (pairB) {
                         int b0 = rbase + ryB;  b0 -= b0 >= NR ? NR : 0;
                         int b1 = b0 + d;       b1 -= b1 >= NR ? NR : 0;
                         int b2 = b1 + d;       b2 -= b2 >= NR ? NR : 0;
-                        const uint4* tB[3] = {ring + b0 * rowch + xB * 8 + cg, ring + b1 * rowch + xB * 8 + cg,
-                                              ring + b2 * rowch + xB * 8 + cg};
+                        const unsigned tB[3] = {lds0 + (unsigned)(b0 * rowch + xB * 8 + cg) * 16u,
+                                                lds0 + (unsigned)(b1 * rowch + xB * 8 + cg) * 16u,
+                                                lds0 + (unsigned)(b2 * rowch + xB * 8 + cg) * 16u};
                         const uint4 dA = dq[2 * kp], dB = dq[(2 * kp + 1 < kDw4K) ? 2 * kp + 1 : 2 * kp];
                         unsigned dl[4], dh[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { dl[i] = pair_lo(wsel(dA, i), wsel(dB, i)); dh[i] = pair_hi(wsel(dA, i), wsel(dB, i)); }
+                        // one filter row (3 taps of A, 3 of B) is requested ahead of the row being consumed
+                        u32x4d fa[2][3], fb[2][3];
 #pragma unroll
-                        for (int a = 0; a < 3; ++a)
+                        for (int q = 0; q < 3; ++q) { dw_lds_rd16(fa[0][q], tA[0] + q * qd); dw_lds_rd16(fb[0][q], tB[0] + q * qd); }
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            if (a < 2) {
+#pragma unroll
+                                for (int q = 0; q < 3; ++q) {
+                                    dw_lds_rd16(fa[(a + 1) & 1][q], tA[a + 1] + q * qd);
+                                    dw_lds_rd16(fb[(a + 1) & 1][q], tB[a + 1] + q * qd);
+                                }
+                                dw_lds_wait<6>(fa[a & 1][0], fa[a & 1][1], fa[a & 1][2], fb[a & 1][0], fb[a & 1][1], fb[a & 1][2]);
+                            } else {
+                                dw_lds_wait<0>(fa[a & 1][0], fa[a & 1][1], fa[a & 1][2], fb[a & 1][0], fb[a & 1][1], fb[a & 1][2]);
+                            }
 #pragma unroll
                             for (int q = 0; q < 3; ++q) {
-                                const uint4 va = tA[a][q * d * 8], vb = tB[a][q * d * 8];
+                                const u32x4d va = fa[a & 1][q], vb = fb[a & 1][q];
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
                                     const unsigned ua = wsel(va, i), ub = wsel(vb, i);
@@ -828,13 +926,21 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
                                     acc2[a * 3 + q][2 * i + 1] = dot2bf(pair_hi(ua, ub), dh[i], acc2[a * 3 + q][2 * i + 1]);
                                 }
                             }
+                        }
                     } else {
                         const uint4 dA = dq[2 * kp];
+                        u32x4d fa[9];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) dw_lds_rd16(fa[a * 3 + q], tA[a] + q * qd);
+                        dw_lds_wait<3>(fa[0], fa[1], fa[2], fa[3], fa[4], fa[5]);
+                        dw_lds_wait<0>(fa[6], fa[7], fa[8]);
 #pragma unroll
                         for (int a = 0; a < 3; ++a)
 #pragma unroll
                             for (int q = 0; q < 3; ++q) {
-                                const uint4 va = tA[a][q * d * 8];
+                                const u32x4d va = fa[a * 3 + q];
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
                                     const unsigned ua = wsel(va, i), ud = wsel(dA, i);

@@ -16,7 +16,8 @@ from distributedpytorch_amd import ops  # noqa: E402
 SHAPES = [  # name, count, C, HW, dil
     ("entry.128@129", 2, 128, 129, 1),
     ("entry.256@65", 2, 256, 65, 1),
-    ("middle.728@65.d2", 51, 728, 65, 2),
+    ("middle.728@65.d2", 0, 728, 65, 2),
+    ("middle.768@65.d2", 51, 768, 65, 2),      # the 728-channel flow as it is stored (models/xception.py)
     ("exit.1024@65.d2", 1, 1024, 65, 2),
     ("exit.1536@65.d4", 2, 1536, 65, 4),
 ]
