@@ -515,14 +515,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                 constexpr int NR = BM / RPP;
                 constexpr int RG = NR % 8 == 0 ? 8 : (NR % 6 == 0 ? 6 : (NR % 4 == 0 ? 4 : (NR % 3 == 0 ? 3 : (NR % 2 == 0 ? 2 : 1))));
                 const bool col_ok = gcol < p.Cout;
+                const int gcl = col_ok ? gcol : 0;
                 for (int r0 = 0; r0 < BM; r0 += RG * RPP) {
                     uint4 vr[RG];
                     bool ok[RG];
+                    // (no branch around a load: rows / columns beyond the tensor re-read its last row / first columns.
+                    // With a load under a branch hipcc cannot count what is outstanding and waits vmcnt(0) before
+                    // every row — i.e. for the previous row's STORE, one exposed write round trip per row.)
 #pragma unroll
                     for (int g = 0; g < RG; ++g) {
                         const int m = m0 + r0 + g * RPP + rsub;
                         ok[g] = (m < p.M) && col_ok;
-                        vr[g] = ok[g] ? *reinterpret_cast<const uint4*>(resp + (long)m * p.ldres + gcol) : make_uint4(0, 0, 0, 0);
+                        vr[g] = *reinterpret_cast<const uint4*>(resp + (long)min(m, p.M - 1) * p.ldres + gcl);
                     }
 #pragma unroll
                     for (int g = 0; g < RG; ++g) {
@@ -555,6 +559,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             const bf16_raw* __restrict__ resp = p.res;
             bf16_raw* __restrict__ yout = p.y;
             const bool col_ok = gcol < p.Cout;
+            const int gcl = col_ok ? gcol : 0;
             float mu[8], is[8], sc[8], sh[8], s1[8], s2[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -570,16 +575,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                 uint4 vx[GRP], va[GRP], vr[GRP];
                 unsigned vm[GRP];
                 bool ok[GRP];
+                // No per-row branch around a load (rows / columns beyond the tensor re-read its last row / first
+                // columns; an absent operand is one uniform branch around its whole batch): with loads under
+                // per-row branches hipcc cannot count what is outstanding and waits vmcnt(0) before every row — for
+                // the previous row's STORE, one exposed write round trip per row.
+                long off[GRP];
 #pragma unroll
                 for (int g = 0; g < GRP; ++g) {
                     const int m = m0 + r0 + g * RPP + rsub;
                     ok[g] = (m < p.M) && col_ok;
-                    const long off = (long)m * p.Cout + gcol;
-                    vx[g] = ok[g] ? *reinterpret_cast<const uint4*>(bnx + off) : make_uint4(0, 0, 0, 0);
-                    va[g] = (ok[g] && bna) ? *reinterpret_cast<const uint4*>(bna + off) : make_uint4(0, 0, 0, 0);
-                    vm[g] = (ok[g] && bnm) ? bnm[off >> 3] : 0u;
-                    vr[g] = (ok[g] && resp) ? *reinterpret_cast<const uint4*>(resp + (long)m * p.ldres + gcol)
-                                            : make_uint4(0, 0, 0, 0);
+                    off[g] = (long)min(m, p.M - 1) * p.Cout + gcl;
+                    vx[g] = *reinterpret_cast<const uint4*>(bnx + off[g]);
+                }
+                if (bna) {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) va[g] = *reinterpret_cast<const uint4*>(bna + off[g]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) va[g] = make_uint4(0, 0, 0, 0);
+                }
+                if (bnm) {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) vm[g] = bnm[off[g] >> 3];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) vm[g] = 0u;
+                }
+                if (resp) {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g)
+                        vr[g] = *reinterpret_cast<const uint4*>(resp + (long)min(m0 + r0 + g * RPP + rsub, p.M - 1) * p.ldres + gcl);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) vr[g] = make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
                 for (int g = 0; g < GRP; ++g) {

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import threading
 
 import torch
@@ -104,8 +105,14 @@ def lib() -> ctypes.CDLL:
     if _lib is None:
         with _lock:
             if _lib is None:
-                _ensure_current()
-                _lib = ctypes.CDLL(LIB_PATH)
+                alt = os.environ.get("DPAMD_HIP_LIB")          # A/B runs against a library built from another tree
+                if alt:
+                    print(f"[dpamd] DPAMD_HIP_LIB: loading {alt} instead of the in-tree library", file=sys.stderr, flush=True)
+                    _build_info.update(source_hash="(DPAMD_HIP_LIB)", lib_hash=os.path.basename(alt), rebuilt=False)
+                    _lib = ctypes.CDLL(alt)
+                else:
+                    _ensure_current()
+                    _lib = ctypes.CDLL(LIB_PATH)
     return _lib
 
 

@@ -170,11 +170,11 @@ def test_conv_beyond_2gib_takes_first_generation_kernels():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("name,kwargs,size", [
-    ("deeplabv3plus_xception65", dict(output_stride=8), 129),
-    ("deeplabv3plus_resnet101", dict(), 257),
+@pytest.mark.parametrize("name,kwargs,size,gain,floor,margin", [
+    ("deeplabv3plus_xception65", dict(output_stride=8), 129, 0.08, 0.75, 0.12),
+    ("deeplabv3plus_resnet101", dict(), 257, 0.15, 0.65, 0.15),
 ])
-def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
+def test_model_training_step_matches_fp32_cpu(name, kwargs, size, gain, floor, margin):
     """One training step (batch statistics) on the kernels against the same model in fp32 on the CPU's torch path:
     loss and the gradients of every convolution.
 
@@ -182,7 +182,12 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
     gradients to a median cosine of 0.42 (X65) / 0.04 (R101) against themselves (tools/diag_model_step.py,
     gpurun_out/q/diag_*.log) — so the BatchNorm closing each residual branch gets gamma x 0.15 (a network near the
     identity, as under zero-init-residual).  There the fp32 noise floor is 0.98, the bf16 kernels land at 0.73-0.87
-    with OR without the fused paths, and a wiring error in a fused path shows as fused << plain."""
+    with OR without the fused paths, and a wiring error in a fused path shows as fused << plain.
+
+    Xception-65 (20 residual blocks, 768-wide stored flow) at x 0.15 spreads over 0.44-0.90 from run to run for
+    EITHER variant and EITHER of two library versions (gpurun_out/bh: fp32 atomics sum in launch order); at x 0.08 /
+    x 0.04 nine runs land in 0.878-0.934 (gpurun_out/bi), while x 0.06 sits at 0.69 / 0.71 (the level depends on the draw more than on the gain): that model runs at the
+    measured x 0.08 with a floor of 0.75."""
     from distributedpytorch_amd.models import build_model
     from distributedpytorch_amd.ops import SoftmaxCrossEntropy, _hip_conv, sepconv
     from distributedpytorch_amd.parallel import TrainEngine
@@ -194,7 +199,7 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
                 m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.3)
         for k, p in m_cpu.named_parameters():
             if k.endswith("bn3.weight") or (".rep." in k and k.endswith(".bn.weight") and not k.endswith("sep.bn.weight")):
-                p.mul_(0.15)
+                p.mul_(float(os.environ.get("DPAMD_TEST_RES_GAIN", gain)))
     if hasattr(getattr(m_cpu, "backbone", None), "zero_pad_channels"):
         m_cpu.backbone.zero_pad_channels()      # Xception's padding channels: zero again after the re-initialisation
     for m in m_cpu.modules():            # dropout off: the fused counter-based generator is not torch's
@@ -240,8 +245,8 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size):
     # that rounds differently flips ReLU masks downstream): 0.73-0.86 for either variant over seven runs
     # (gpurun_out/al, am) — so the floor and the fused-vs-plain margin are set from that spread; a wiring error
     # in a fused path lands far below both (0.04-0.4).
-    assert last_f > 0.995 and med_f > 0.65, (last_f, med_f)
-    assert med_f > med_p - 0.15, (med_f, med_p)
+    assert last_f > 0.995 and med_f > floor, (last_f, med_f)
+    assert med_f > med_p - margin, (med_f, med_p)
 
 
 def test_xception_padded_flow_stays_the_728_channel_network(tmp_path):
