@@ -40,8 +40,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DPAMD_BENCH_BATCH", "128")),
-                    help="per-GPU batch (128 x 513² holds 55 GiB of the 288 GB HBM3E)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DPAMD_BENCH_BATCH", "0")),
+                    help="per-GPU batch; default 256 for the headline model on the kernels (110 GiB of the 288 GB HBM3E; layers "
+                         "whose activations pass 2 GiB run as image chunks), 128 otherwise")
     ap.add_argument("--crop", type=int, default=513)
     ap.add_argument("--model", default="deeplabv3plus_resnet101")
     ap.add_argument("--in-channels", type=int, default=None, help="default: 3 (semseg) / 4 (instance)")
@@ -71,7 +72,15 @@ def load_self_baseline(model: str, crop: int, batch: int):
             table = json.load(f)
     except (OSError, ValueError):
         return None
-    return table.get(_baseline_key(model, crop), {}).get(str(batch))
+    per_batch = table.get(_baseline_key(model, crop), {})
+    rec = per_batch.get(str(batch))
+    if rec is None and per_batch:
+        # no stock run at this batch (its MIOpen search alone passes a GPU call's time limit at 256): the largest
+        # measured stock batch, flagged as NOT equal-batch (stock: 252 / 315 / 343 img/s at 32 / 64 / 128)
+        nearest = max((int(b) for b in per_batch if int(b) <= batch), default=None)
+        if nearest is not None:
+            rec = dict(per_batch[str(nearest)], equal_batch=False)
+    return rec
 
 
 def record_self_baseline(model: str, crop: int, batch: int, rec: dict) -> None:
@@ -142,6 +151,11 @@ def main():
         criterion = SoftmaxCrossEntropy(255)
     engine = TrainEngine(model, criterion, lr=5e-8 if instance else 0.007, momentum=0.9, weight_decay=5e-4,
                          device=info.device, bucket_mb=args.bucket_mb)
+    if args.batch <= 0:
+        # sized for the 288 GB of HBM3E: 984-986 img/s at 256 against 955-968 at 128 (profiles/r2_native_v38_b256_*);
+        # 384 buys nothing more.  Other models / the stock path keep 128 (their measured configurations).
+        args.batch = 256 if (on_gpu and args.impl == "native" and args.model == "deeplabv3plus_resnet101"
+                             and not instance and args.crop == 513) else 128
     B, S = args.batch, args.crop
     g = torch.Generator().manual_seed(100 + info.rank)
     raw_img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(info.device)
@@ -254,7 +268,11 @@ def main():
             if args.impl == "native" and base is not None:
                 # the reference publishes nothing (vs_baseline stays null); the self-established
                 # baseline is the stock PyTorch-ROCm op path, same model code, same GPU type, SAME per-GPU batch
-                rec["self_baseline"] = dict(base, ratio_per_gpu_equal_batch=round(ips / world / base["img_s"], 3))
+                ratio = round(ips / world / base["img_s"], 3)
+                if base.get("equal_batch", True):
+                    rec["self_baseline"] = dict(base, ratio_per_gpu_equal_batch=ratio)
+                else:
+                    rec["self_baseline"] = dict(base, **{f"ratio_per_gpu_vs_stock_at_batch_{base['batch']}": ratio})
             if args.impl == "stock" and args.record_baseline and world == 1:
                 record_self_baseline(args.model, S, B, {
                     "batch": B, "img_s": round(ips, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 2),

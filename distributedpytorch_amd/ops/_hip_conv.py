@@ -56,6 +56,21 @@ def _round8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
+# The LDS-DMA kernels address their streamed operands with 32-bit byte offsets (< 2^31 - 2^24).  A batch whose
+# activation passes that is cut into image chunks, one launch each, on the SAME kernels: batch statistics, fused
+# BN-backward sums and weight gradients accumulate by atomics into the same buffers, so the chunks need no combine
+# step.  (Round 1 sent such layers - per-GPU batch > 224 of the headline model - to the first-generation kernel.)
+_OFFSET_LIMIT = (1 << 31) - (1 << 24)
+_CHUNKING = os.environ.get("DPAMD_CONV_BATCH_CHUNKS", "1") != "0"
+
+
+def _images_per_launch(n: int, *streamed) -> int:
+    per_img = max(t.numel() // n * t.element_size() for t in streamed if t is not None)
+    if not _CHUNKING or n <= 1 or per_img * n < _OFFSET_LIMIT:
+        return n
+    return max(1, (_OFFSET_LIMIT - 1) // per_img)
+
+
 def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
           pad: Tuple[int, int], dil: Tuple[int, int], bias: Optional[torch.Tensor] = None,
           stats: Optional[torch.Tensor] = None, tile: int = 0, cfg: Optional[int] = None,
@@ -92,6 +107,13 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
                 or not stats.is_contiguous():
             raise ValueError("igemm: stats must be contiguous fp32 [R, 2, Cout]")
         reps = stats.shape[0]
+    nper = _images_per_launch(n, x)
+    if nper < n:
+        for n0 in range(0, n, nper):
+            n1 = min(n, n0 + nper)
+            igemm(x[n0:n1], w_krsc, out_hw, smul, sdiv, pad, dil, bias, stats, tile, cfg,
+                  residual[n0:n1] if residual is not None else None, y[n0:n1], residual_affine)
+        return y
     args = (B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(bias), B.ptr(stats), reps, n, hi, wi, cin,
             ho, wo, cout, r, s, smul, sdiv, pad[0], pad[1], dil[0], dil[1], cout)
     if cfg is None:
@@ -264,13 +286,23 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     reps = stat_replicas(n * ho * wo)
 
+    nper = _images_per_launch(n, dy)
+    bits_img = (ho * wo * (cout // 8)) if bits is not None else 0
+
     def launch(c, sums_ptr, stream):
-        if bits is not None:
-            _lib().dp_conv_set_bnmask(B.ptr(bits))       # consumed by the launch below
-        return _lib().dp_conv_igemm2b(B.ptr(dy), B.ptr(wt), B.ptr(y), n, hi, wi, cin, ho, wo, cout, r, s, 1, sdiv,
-                                      pad[0], pad[1], dil[0], dil[1], c, B.ptr(residual), B.ptr(bx), B.ptr(ba),
-                                      B.ptr(holder["mean"]), B.ptr(holder["invstd"]), B.ptr(holder.get("w")),
-                                      B.ptr(holder.get("b")), sums_ptr, reps, stream)
+        st = 0
+        for n0 in range(0, n, nper):         # (one launch unless the gradient passes the kernels' 32-bit offsets)
+            n1 = min(n, n0 + nper)
+            sl = (lambda t: t[n0:n1] if t is not None else None)
+            if bits is not None:
+                _lib().dp_conv_set_bnmask(B.ptr(bits.view(-1)[n0 * bits_img:]))       # consumed by the launch below
+            st = _lib().dp_conv_igemm2b(B.ptr(dy[n0:n1]), B.ptr(wt), B.ptr(y[n0:n1]), n1 - n0, hi, wi, cin, ho, wo, cout,
+                                        r, s, 1, sdiv, pad[0], pad[1], dil[0], dil[1], c, B.ptr(sl(residual)),
+                                        B.ptr(bx[n0:n1]), B.ptr(sl(ba)), B.ptr(holder["mean"]), B.ptr(holder["invstd"]),
+                                        B.ptr(holder.get("w")), B.ptr(holder.get("b")), sums_ptr, reps, stream)
+            if st != 0:
+                break
+        return st
     if cfg is None:
         if _AUTOTUNE:
             scratch = torch.zeros(reps * 2 * cout, dtype=torch.float32, device=dy.device)
@@ -346,6 +378,11 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
     else:
         dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
                          memory_format=torch.channels_last).zero_()
+    nper = _images_per_launch(n, x, dy)
+    if nper < n and not _WGRAD_GEN1:
+        for n0 in range(0, n, nper):         # split-K over image chunks: every launch adds into the same dw
+            wgrad(dy[n0:n0 + nper], x[n0:n0 + nper], wshape, stride, pad, dil, out=dw, splits=splits)
+        return dw
     if splits == 0 and _AUTOTUNE and not _WGRAD_GEN1:
         key = ("wgrad", n, hi, wi, cin, ho, wo, cout, r, s, tuple(stride), tuple(pad), tuple(dil))
         splits = _TUNED.get(key)
@@ -601,9 +638,17 @@ class _StemConv(torch.autograd.Function):
         dy = as_nhwc(dy)
         dwp = workspace.zeros(cout * r * _STEM_WINDOW, dy.device)
 
+        nper = _images_per_launch(n, dy, xp)
+
         def run(dst, splits, stream):
-            return _lib().dp_conv_wgrad_win(B.ptr(dy), B.ptr(xp), dst, n, hi, wp_px, _STEM_WINDOW, 4, ho, wo,
-                                            cout, r, stride[0], padding[0], splits, stream)
+            st = 0
+            for n0 in range(0, n, nper):       # (one launch unless dy passes the kernel's 32-bit offsets)
+                n1 = min(n, n0 + nper)
+                st = _lib().dp_conv_wgrad_win(B.ptr(dy[n0:n1]), B.ptr(xp[n0:n1]), dst, n1 - n0, hi, wp_px, _STEM_WINDOW,
+                                              4, ho, wo, cout, r, stride[0], padding[0], splits, stream)
+                if st != 0:
+                    break
+            return st
         splits = 0
         if _AUTOTUNE:
             key = ("stem_wgrad", n, hi, wp_px, ho, wo, cout, r, stride[0], padding[0])

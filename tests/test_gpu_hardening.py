@@ -123,10 +123,11 @@ def test_headline_problem_at_batch_32(case):
         assert channel_rel(wh.grad, wfull.grad, dim=0) < 2e-2
 
 
-def test_conv_beyond_2gib_takes_first_generation_kernels():
+def test_conv_beyond_2gib_runs_as_batch_chunks():
     """8 x 128 x 1025 x 1025 bf16 = 2.15 GB: past the 32-bit byte offsets of the second-generation kernels
-    (dp_conv_igemm2 returns -4).  The whole-batch results must equal the per-image launches (269 MB each: second
-    generation) and an fp32 CPU convolution of sampled rows."""
+    (dp_conv_igemm2 returns -4 for the whole batch; ops/_hip_conv.py cuts it into image chunks on the same kernels).
+    The whole-batch results must equal the per-image launches (269 MB each) and an fp32 CPU convolution of
+    sampled rows."""
     from distributedpytorch_amd.ops import _hip_conv
     n, cin, cout, hw = 8, 128, 16, 1025
     torch.manual_seed(2)
@@ -140,6 +141,7 @@ def test_conv_beyond_2gib_takes_first_generation_kernels():
         rc = _lib().dp_conv_igemm2(B.ptr(x), B.ptr(w), B.ptr(y_probe), None, None, 1, n, hw, hw, cin, hw, hw, cout, k, k,
                                    1, 1, pad, pad, 1, 1, cout, 1, B.stream_ptr())
         assert rc == -4, f"second-generation kernel accepted a {x.numel() * 2 / 2**30:.2f} GiB input (rc {rc})"
+        assert 1 <= _hip_conv._images_per_launch(n, x) < n
         xh = x.detach().requires_grad_(True)
         wh = w.float().requires_grad_(True)
         y = ops.conv2d(xh, wh, None, 1, pad, 1)
@@ -290,3 +292,43 @@ def test_xception_padded_flow_stays_the_728_channel_network(tmp_path):
     assert plain.backbone.mid_physical == 728
     res = checkpoint.load_weights(path, plain)
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_batch_chunks_equal_one_launch(monkeypatch):
+    """The image-chunk path of the convolution wrappers (taken beyond 2 GiB) forced on a small conv-BN-ReLU stack:
+    forward, fused BN-backward data gradients (with the 1-bit mask of a residual output) and weight gradients must
+    equal the one-launch results up to the order of the atomic sums."""
+    from distributedpytorch_amd.ops import _hip_conv
+    torch.manual_seed(3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = ops.Conv2d(32, 64, 3, padding=1, bias=False); self.b1 = ops.BatchNorm2d(64)
+            self.c2 = ops.Conv2d(64, 64, 1, bias=False); self.b2 = ops.BatchNorm2d(64)
+            self.c3 = ops.Conv2d(64, 32, 3, padding=2, dilation=2, bias=False); self.b3 = ops.BatchNorm2d(32)
+
+        def forward(self, x):
+            a = ops.conv_bn_act(self.c1, self.b1, x, relu=True)
+            b = ops.conv_bn_act(self.c2, self.b2, a, relu=True, residual=a)
+            return ops.conv_bn_act(self.c3, self.b3, b, relu=True)
+
+    net = Net().to(DEV).train()
+    x = _nhwc(torch.randn(6, 32, 33, 33, device=DEV).to(torch.bfloat16))
+    gy = None
+    res = {}
+    for tag, limit in (("one", _hip_conv._OFFSET_LIMIT), ("chunks", 2 * 32 * 33 * 33 * 2 + 1)):
+        monkeypatch.setattr(_hip_conv, "_OFFSET_LIMIT", limit)
+        net.zero_grad(set_to_none=True)
+        xi = x.detach().clone(memory_format=torch.channels_last).requires_grad_(True)
+        y = net(xi)
+        if gy is None:
+            gy = _nhwc(torch.randn_like(y))
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res[tag] = (y.detach().float(), xi.grad.float(), [p.grad.detach().float().clone() for p in net.parameters()])
+    assert _hip_conv._images_per_launch(6, x) == 2          # (the patched limit: two images per launch)
+    (y1, dx1, g1), (y2, dx2, g2) = res["one"], res["chunks"]
+    assert cosine(y1, y2) > 0.99999 and cosine(dx1, dx2) > 0.9999
+    for a, b in zip(g1, g2):
+        assert cosine(a, b) > 0.9999
