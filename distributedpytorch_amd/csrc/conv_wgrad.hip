@@ -371,6 +371,36 @@ __global__ __launch_bounds__(kThreads * G, NST == 3 ? 1 : 2) void conv_wgrad2_ke
         }
     };
 
+    // the same stage in three parts (dy pieces 0-1, dy pieces 2-3, the x pieces), for the 16x16x32 loop below
+    auto issue_dy2 = [&](int buf, int i0) {
+        unsigned char* dbase = smem + buf * STG + grp * TILE_BYTES + w4 * 1024;
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i) {
+            lds_dma16w(rdy, dbase + i * 4096, dy_voff[i], 0);
+            dy_voff[i] += dy_step;
+        }
+    };
+    auto issue_x = [&](int buf) {
+        unsigned char* xbase = smem + buf * STG + XOFF + wave * 1024;
+        if (UNIT) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                lds_dma16w(rx, xbase + i * (4096 * G), x_voff[i], 0);
+                x_voff[i] += x_step;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int iy = poy[i] * p.stride_h + tdy, ix = pox[i] * p.stride_w + tdx;
+                const bool ok = n_ok & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+                lds_dma16w(rx, xbase + i * (4096 * G), ok ? x_voff[i] + (unsigned)tap_bytes : kOOBw, 0);
+                pox[i] += adv_x; poy[i] += adv_y; x_voff[i] += adv_bytes;
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; x_voff[i] += wrapx_bytes; }
+                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; x_voff[i] += wrapy_bytes; }
+            }
+        }
+    };
+
     if constexpr (!MF16) {
     f32x16 acc[2][2];
 #pragma unroll
@@ -563,24 +593,29 @@ __global__ __launch_bounds__(kThreads * G, NST == 3 ? 1 : 2) void conv_wgrad2_ke
 #ifdef DP_STAMP
         if (t == 0) WG_STAMP_AT(2);
 #endif
-        if (NST == 3) {
-            if (t + 2 < nsteps) issue_stage(cur == 0 ? 2 : cur - 1);
-        } else {
-            if (t + 1 < nsteps) issue_stage(cur ^ 1);
-        }
+        // The next stage's LDS-DMA pieces are issued in three groups BETWEEN the MFMA groups of the step, not as one
+        // burst behind the barrier: eight waves issuing six 1-KiB pieces each at the same moment, next to their first
+        // 16 fragment reads, fill the texture-address FIFOs (SQ_VMEM_TA_CMD/ADDR_FIFO_FULL) and each piece then holds
+        // its wave for 100+ cycles (MI355X_MICROARCH: issue cost of an LDS-DMA piece by what the phase carries).
+        const bool more3 = NST == 3 && t + 2 < nsteps;
+        const int nslot = cur == 0 ? 2 : cur - 1;
+        if (NST != 3 && t + 1 < nsteps) issue_stage(cur ^ 1);
         // pixels 0-31 of the step into set 0, 32-63 into set 1; at most 16 reads outstanding
         W16_READ_A(0, 0, 0)
         W16_READ_B(0, 0)
         W16_READ_A(0, 0, 2)
         W16_WAIT_A01B(0, 4);
         W16_MFMA(0, 0)
+        if (more3) issue_dy2(nslot, 0);
         W16_READ_A(1, 1, 0)
         W16_READ_B(1, 1)
         W16_WAIT_A23(0, 12);
         W16_MFMA(0, 2)
+        if (more3) issue_dy2(nslot, 2);
         W16_READ_A(1, 1, 2)
         W16_WAIT_A01B(1, 4);
         W16_MFMA(1, 0)
+        if (more3) issue_x(nslot);
         W16_WAIT_A23(1, 0);
         W16_MFMA(1, 2)
         const bool wrap = cur == NST - 1;
