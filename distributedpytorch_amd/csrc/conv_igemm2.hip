@@ -88,6 +88,14 @@ struct Conv2Args {
 #define DP_STAMP_AT(i)
 #endif
 
+// Spreading a stage's LDS-DMA pieces over the MFMA groups of the K loop (what gained 4-6 % in the weight-gradient
+// kernel's 3-stage ring) is 1 % SLOWER here: with the 2-stage rings the tiles run, a piece issued late in step t has
+// less than a step left to land before step t + 1 waits for it (profiles/r2_conv_dma_spread_negative.log).  Off.
+#ifndef DP_SPREAD_DMA
+#define DP_SPREAD_DMA 0
+#endif
+constexpr bool kSpreadDma = DP_SPREAD_DMA != 0;
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -278,38 +286,50 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         while (kr < p.R && !((tile_mask >> (kr * p.S + ks)) & 1u)) { if (++ks == p.S) { ks = 0; ++kr; } }
     }
     const int sdr = (1 << p.sdl) - 1;
-    auto issue_stage = [&](int buf) {
-        unsigned char* abase = smem + buf * STAGE + wave * 1024;       // one wave-instruction fills 1 KiB
-        unsigned char* bbase = abase + A_BYTES;
-        const unsigned w_soff = (unsigned)(((kr * p.S + ks) * p.Cin + kc * BK) * 2);
+    // A stage is issued piece by piece (one piece = one 1-KiB wave instruction): stage_begin does the uniform address
+    // math, stage_piece(j) issues operand piece j (0 .. AR-1: pixels, AR .. AR+BR-1: weights), stage_end advances the
+    // K-step iterator.  The prologue issues whole stages; the K loop spreads a stage's pieces between its MFMA groups.
+    struct StageCtx { unsigned char* abase; unsigned char* bbase; unsigned w_soff, a_soff, tapbit; bool cv; };
+    auto stage_begin = [&](int buf) -> StageCtx {
+        StageCtx c;
+        c.abase = smem + buf * STAGE + wave * 1024;       // one wave-instruction fills 1 KiB
+        c.bbase = c.abase + A_BYTES;
+        c.w_soff = (unsigned)(((kr * p.S + ks) * p.Cin + kc * BK) * 2);
+        c.cv = !p.ctail || (lc * 8 < p.Cin - kc * BK);
         if (UNIT) {
-            const unsigned a_soff = (unsigned)(kc * BK * 2);
-            if (p.ctail) {
-                const bool cv = lc * 8 < p.Cin - kc * BK;
-#pragma unroll
-                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * ROWB), cv ? a_voff[i] : kOOB, a_soff);
-            } else {
-#pragma unroll
-                for (int i = 0; i < AR; ++i) lds_dma16(rx, abase + i * (RPR * ROWB), a_voff[i], a_soff);
-            }
+            c.a_soff = (unsigned)(kc * BK * 2);
+            c.tapbit = 0;
         } else {
             const int cdy = (kr * p.dil_h + sdr) >> p.sdl, cdx = (ks * p.dil_w + sdr) >> p.sdl;   // ceil(tap / sdiv)
-            const unsigned a_soff = (unsigned)(((cdy * p.Wi + cdx) * p.ldx + kc * BK) * 2);
-            const unsigned tapbit = 1u << (kr * p.S + ks);
-            const bool cv = !p.ctail || (lc * 8 < p.Cin - kc * BK);
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const bool ok = ((a_mask[i] & tapbit) != 0) & cv;
-                // the sum is formed per lane: the base may be "negative" (padding) and only base+tap is in range
-                lds_dma16(rx, abase + i * (RPR * ROWB), ok ? a_voff[i] + a_soff : kOOB, 0);
-            }
+            c.a_soff = (unsigned)(((cdy * p.Wi + cdx) * p.ldx + kc * BK) * 2);
+            c.tapbit = 1u << (kr * p.S + ks);
         }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) lds_dma16(rw, bbase + i * (RPR * ROWB), b_voff[i], w_soff);
+        return c;
+    };
+    auto stage_piece = [&](const StageCtx& c, int j) {
+        if (j < AR) {
+            if (UNIT) {
+                lds_dma16(rx, c.abase + j * (RPR * ROWB), c.cv ? a_voff[j] : kOOB, c.a_soff);
+            } else {
+                const bool ok = ((a_mask[j] & c.tapbit) != 0) & c.cv;
+                // the sum is formed per lane: the base may be "negative" (padding) and only base+tap is in range
+                lds_dma16(rx, c.abase + j * (RPR * ROWB), ok ? a_voff[j] + c.a_soff : kOOB, 0);
+            }
+        } else {
+            lds_dma16(rw, c.bbase + (j - AR) * (RPR * ROWB), b_voff[j - AR], c.w_soff);
+        }
+    };
+    auto stage_end = [&]() {
         if (++kc == p.csteps) {
             kc = 0;
             do { if (++ks == p.S) { ks = 0; ++kr; } } while (!UNIT && kr < p.R && !((tile_mask >> (kr * p.S + ks)) & 1u));
         }
+    };
+    auto issue_stage = [&](int buf) {
+        const StageCtx c = stage_begin(buf);
+#pragma unroll
+        for (int j = 0; j < AR + BR; ++j) stage_piece(c, j);
+        stage_end();
     };
 
     // ---- accumulators: acc[mi][ni][j] = out(pixel tile mi, lane&15 ; channel tile ni, (lane>>4)*4 + j) ----
@@ -344,13 +364,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
 #ifdef DP_STAMP
         if (t == 0) DP_STAMP_AT(2);
 #endif
-        if (t + NST - 1 < ksteps && !(p.ablate & 1)) {
-            int ib = buf + NST - 1;
-            if (ib >= NST) ib -= NST;
-            issue_stage(ib);
-        }
+        const bool do_issue = t + NST - 1 < ksteps && !(p.ablate & 1);      // uniform
+        int ib = buf + NST - 1;
+        if (ib >= NST) ib -= NST;
+        // PIPE: the stage's pieces go out between the MFMA groups below, SPREAD pieces per group, not as one burst
+        // of AR + BR wave instructions behind the barrier (every wave of the CU doing the same at the same moment
+        // fills the texture-address FIFOs and each piece then holds its wave for 100+ cycles; measured on the
+        // weight-gradient kernel: K loop -4...-6 %, profiles/r2_wgrad_dma_spread_stamps.txt)
+        if (do_issue && (!PIPE || !kSpreadDma)) issue_stage(ib);
         if (p.ablate & 4) { if (++buf == NST) buf = 0; continue; }
         if (PIPE) {
+            StageCtx sc{};
+            if (kSpreadDma && do_issue) sc = stage_begin(ib);
             // Left to itself hipcc sinks every fragment read to just before its first MFMA (2 reads, wait,
             // 8 MFMAs, 2 reads, wait, ...: the ISA of the first version), so each wave exposes an LDS
             // round trip per pair of pixel tiles and reads and MFMAs of a wave never overlap — the time of
@@ -392,6 +417,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                     else if (newer == PA) wait_lgkm<PA>();
                     else wait_lgkm<NI + PA>();
                     __builtin_amdgcn_sched_barrier(0);
+                    if (kSpreadDma) {
+                        // this group's share of the next stage's pieces (the last group takes what is left)
+                        constexpr int NG = KK * G, PPG = (AR + BR + NG - 1) / NG;
+                        const int gi = kk * G + g;
+                        if (do_issue) {
+#pragma unroll
+                            for (int j = gi * PPG; j < (gi + 1 == NG ? AR + BR : (gi + 1) * PPG); ++j)
+                                if (j < AR + BR) stage_piece(sc, j);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int a = 0; a < PA; ++a)
 #pragma unroll
@@ -401,6 +437,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                                 acc[g * PA + a][ni], 0, 0, 0);
                 }
             }
+            if (kSpreadDma && do_issue) stage_end();
         } else {
         const unsigned char* St = smem + buf * STAGE;
 #pragma unroll
