@@ -689,19 +689,25 @@ class _DepthwiseConv(torch.autograd.Function):
         y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ctx.set_materialize_grads(False)
         stats = None
+        # image chunks when a tensor passes the rolling-window kernels' 32-bit offsets (as the dense wrappers do)
+        nper = _images_per_launch(n, x, y)
+        spans = [(n0, min(n, n0 + nper)) for n0 in range(0, n, nper)]
         if with_stats:
             # BatchNorm statistics from the kernel's own accumulators (csrc/depthwise.hip, Dw3::stats)
             reps = stat_replicas(n * ho * wo)
             stats = workspace.zeros(reps * 2 * c, x.device).view(reps, 2, c)
-            st = _lib().dp_dwconv_fwd_stats(B.ptr(x), B.ptr(w9), B.ptr(y), B.ptr(stats), reps, n, c, hi, wi, ho, wo,
-                                            stride[0], padding[0], padding[1], dilation[0], B.stream_ptr())
-            if st == -2:
-                stats = None                     # shape not taken by the tiled kernel: separate pass below
-            else:
+            for i, (n0, n1) in enumerate(spans):
+                st = _lib().dp_dwconv_fwd_stats(B.ptr(x[n0:n1]), B.ptr(w9), B.ptr(y[n0:n1]), B.ptr(stats), reps, n1 - n0, c,
+                                                hi, wi, ho, wo, stride[0], padding[0], padding[1], dilation[0],
+                                                B.stream_ptr())
+                if st == -2 and i == 0:
+                    stats = None                 # shape not taken by the tiled kernel: separate pass below
+                    break
                 B.check(st, "dwconv_fwd_stats")
         if stats is None:
-            B.check(_lib().dp_dwconv_fwd(B.ptr(x), B.ptr(w9), B.ptr(y), n, c, hi, wi, ho, wo, stride[0], padding[0],
-                                         padding[1], dilation[0], B.stream_ptr()), "dwconv_fwd")
+            for n0, n1 in spans:
+                B.check(_lib().dp_dwconv_fwd(B.ptr(x[n0:n1]), B.ptr(w9), B.ptr(y[n0:n1]), n1 - n0, c, hi, wi, ho, wo,
+                                             stride[0], padding[0], padding[1], dilation[0], B.stream_ptr()), "dwconv_fwd")
         ctx.save_for_backward(x, w9)
         ctx.geom = (stride, padding, dilation, (hi, wi), (ho, wo))
         ctx.weight_param = weight
@@ -729,6 +735,8 @@ class _DepthwiseConv(torch.autograd.Function):
         n, c = x.shape[:2]
         dy = as_nhwc(dy)
         dx = dw = None
+        nper = _images_per_launch(n, x, dy)
+        spans = [(n0, min(n, n0 + nper)) for n0 in range(0, n, nper)]
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if dskip is not None:
@@ -752,20 +760,26 @@ class _DepthwiseConv(torch.autograd.Function):
                     # recomputed from the BatchNorm input the kernel reads anyway (one tensor less to fetch)
                     ba = x if (bx is not None and h.get("mask_from_a")) else None
                     hv = (lambda k: h.get(k) if bx is not None else None)
-                    st = _lib().dp_dwconv_bwd_data_fused(
-                        B.ptr(dy), B.ptr(w9), B.ptr(dx), B.ptr(dskip), B.ptr(ba), B.ptr(bx), B.ptr(hv("mean")),
-                        B.ptr(hv("invstd")), B.ptr(hv("w")), B.ptr(hv("b")), B.ptr(sums), reps, n, c, hi, wi,
-                        dilation[0], B.stream_ptr())
-                    if st != -2:
+                    sl = (lambda t, n0, n1: t[n0:n1] if t is not None else None)
+                    st = 0
+                    for i, (n0, n1) in enumerate(spans):
+                        st = _lib().dp_dwconv_bwd_data_fused(
+                            B.ptr(dy[n0:n1]), B.ptr(w9), B.ptr(dx[n0:n1]), B.ptr(sl(dskip, n0, n1)), B.ptr(sl(ba, n0, n1)),
+                            B.ptr(sl(bx, n0, n1)), B.ptr(hv("mean")), B.ptr(hv("invstd")), B.ptr(hv("w")), B.ptr(hv("b")),
+                            B.ptr(sums), reps, n1 - n0, c, hi, wi, dilation[0], B.stream_ptr())
+                        if st == -2 and i == 0:
+                            break
                         B.check(st, "dwconv_bwd_data_fused")
+                    if st != -2:
                         fused = True
                         if bx is not None:
                             h["sums"] = sums
                             h["dm_ptr"] = dx.data_ptr()
             if not fused:
-                B.check(_lib().dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), n, c, hi, wi, ho, wo, stride[0],
-                                                  padding[0], padding[1], dilation[0], B.stream_ptr()),
-                        "dwconv_bwd_data")
+                for n0, n1 in spans:
+                    B.check(_lib().dp_dwconv_bwd_data(B.ptr(dy[n0:n1]), B.ptr(w9), B.ptr(dx[n0:n1]), n1 - n0, c, hi, wi,
+                                                      ho, wo, stride[0], padding[0], padding[1], dilation[0],
+                                                      B.stream_ptr()), "dwconv_bwd_data")
                 if dskip is not None:
                     dx += dskip
         elif dskip is not None:
@@ -784,9 +798,10 @@ class _DepthwiseConv(torch.autograd.Function):
                 # auxiliary stream beside the MFMA kernels of the next backward nodes and lands in the arena
                 aux = streams.fork(dy.device)
                 with torch.cuda.stream(aux):
-                    B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo,
-                                                        stride[0], padding[0], padding[1], dilation[0],
-                                                        B.stream_ptr()), "dwconv_bwd_weight")
+                    for n0, n1 in spans:
+                        B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(dw9), n1 - n0, c, hi, wi,
+                                                            ho, wo, stride[0], padding[0], padding[1], dilation[0],
+                                                            B.stream_ptr()), "dwconv_bwd_weight")
                     sink.view(c, 9).add_(dw9.t())
                 dy.record_stream(aux)
                 x.record_stream(aux)
@@ -794,9 +809,10 @@ class _DepthwiseConv(torch.autograd.Function):
                 if notify is not None:
                     notify(wp)
             else:
-                B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), n, c, hi, wi, ho, wo, stride[0],
-                                                    padding[0], padding[1], dilation[0], B.stream_ptr()),
-                        "dwconv_bwd_weight")
+                for n0, n1 in spans:
+                    B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(dw9), n1 - n0, c, hi, wi, ho,
+                                                        wo, stride[0], padding[0], padding[1], dilation[0],
+                                                        B.stream_ptr()), "dwconv_bwd_weight")
                 dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
         return dx, dw, None, None, None, None, None, None, None
 

@@ -332,3 +332,33 @@ def test_batch_chunks_equal_one_launch(monkeypatch):
     assert cosine(y1, y2) > 0.99999 and cosine(dx1, dx2) > 0.9999
     for a, b in zip(g1, g2):
         assert cosine(a, b) > 0.9999
+
+
+def test_depthwise_batch_chunks_equal_one_launch(monkeypatch):
+    """The same for the depthwise path: an Xception block (rolling-window depthwise kernels with fused statistics, the
+    fused BN-backward data gradient with shortcut add, weight gradients on the auxiliary stream) in image chunks."""
+    from distributedpytorch_amd.models.xception import XceptionBlock
+    from distributedpytorch_amd.ops import _hip_conv
+    torch.manual_seed(4)
+    blk = torch.nn.Sequential(XceptionBlock(64, 64, 3, dilation=2), XceptionBlock(64, 128, 2, stride=1, dilation=1)).to(DEV).train()
+    x = _nhwc(torch.randn(6, 64, 33, 33, device=DEV).to(torch.bfloat16))
+    gy, res = None, {}
+    big = _hip_conv._OFFSET_LIMIT
+    for tag, limit in (("one", big), ("again", big), ("chunks", 2 * 64 * 33 * 33 * 2 + 1)):
+        monkeypatch.setattr(_hip_conv, "_OFFSET_LIMIT", limit)
+        blk.zero_grad(set_to_none=True)
+        xi = x.detach().clone(memory_format=torch.channels_last).requires_grad_(True)
+        y = blk(xi)
+        if gy is None:
+            gy = _nhwc(torch.randn_like(y))
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res[tag] = (y.detach().float(), xi.grad.float(), [p.grad.detach().float().clone() for p in blk.parameters()])
+    (y1, dx1, g1), (_, dxr, gr), (y2, dx2, g2) = res["one"], res["again"], res["chunks"]
+    assert cosine(y1, y2) > 0.99999 and cosine(dx1, dx2) > cosine(dx1, dxr) - 1e-3
+    # the yardstick is the SAME launch repeated: small cancellation-heavy gradients (the outer BatchNorm scales of a
+    # folded unit: norm 10-20 against 1e3-1e4 of their neighbours) move to 0.94-0.97 from run to run by the order of
+    # the fp32 atomics alone (tools/diag_chunks.py)
+    for a, r, b in zip(g1, gr, g2):
+        if float(a.norm()) > 1e-6:
+            assert cosine(a, b) > min(0.999, cosine(a, r) - 0.05), (cosine(a, b), cosine(a, r))
