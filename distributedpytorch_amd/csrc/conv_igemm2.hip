@@ -94,7 +94,7 @@ struct Conv2Args {
 #ifndef DP_SPREAD_DMA
 #define DP_SPREAD_DMA 0
 #endif
-constexpr bool kSpreadDma = DP_SPREAD_DMA != 0;
+constexpr int kSpreadMode = DP_SPREAD_DMA;      // 0 off, 1 every ring, 2 rings of three stages and more
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -364,6 +364,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
 #ifdef DP_STAMP
         if (t == 0) DP_STAMP_AT(2);
 #endif
+        constexpr bool kSpreadDma = kSpreadMode == 1 || (kSpreadMode == 2 && NST >= 3);
         const bool do_issue = t + NST - 1 < ksteps && !(p.ablate & 1);      // uniform
         int ib = buf + NST - 1;
         if (ib >= NST) ib -= NST;
