@@ -154,8 +154,14 @@ def main():
     if args.batch <= 0:
         # sized for the 288 GB of HBM3E: 984-986 img/s at 256 against 955-968 at 128 (profiles/r2_native_v38_b256_*);
         # 384 buys nothing more.  Other models / the stock path keep 128 (their measured configurations).
-        args.batch = 256 if (on_gpu and args.impl == "native" and args.model == "deeplabv3plus_resnet101"
-                             and not instance and args.crop == 513) else 128
+        if on_gpu and args.impl == "native" and args.model == "deeplabv3plus_resnet101" and not instance and args.crop == 513:
+            args.batch = 256
+        elif "xception" in args.model:
+            args.batch = 64          # output stride 8: 305-314 img/s at 64, nothing more at 96, 234 at 128
+        elif instance:
+            args.batch = 32          # DANet 512x512: 340-345 img/s (352 at 64, 356 at 96)
+        else:
+            args.batch = 128
     B, S = args.batch, args.crop
     g = torch.Generator().manual_seed(100 + info.rank)
     raw_img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(info.device)
