@@ -558,6 +558,11 @@ __global__ __launch_bounds__(kThreads * G, NST == 3 ? 1 : 2) void conv_wgrad2_ke
             }
     }
     s16x4 fa[2][4][2], fb[2][4][2];                     // [set][16-channel block][rd]
+#ifdef DP_WG_PRIO
+#define W16_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#else
+#define W16_PRIO(P)
+#endif
 #define W16_RD(DST, ADDR, KK) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"((KK) * 8192))
 #define W16_READ_A(SET, KK, I0)                                                                                    \
     _Pragma("unroll") for (int i_ = (I0); i_ < (I0) + 2; ++i_) {                                                   \
@@ -575,13 +580,15 @@ __global__ __launch_bounds__(kThreads * G, NST == 3 ? 1 : 2) void conv_wgrad2_ke
     asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                       \
                  : "+v"(fa[SET][2][0]), "+v"(fa[SET][2][1]), "+v"(fa[SET][3][0]), "+v"(fa[SET][3][1]))
 #define W16_MFMA(SET, I0)                                                                                          \
+    W16_PRIO(1);                                                                                                   \
     _Pragma("unroll") for (int i_ = (I0); i_ < (I0) + 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) { \
         typedef __attribute__((ext_vector_type(8))) short s16x8_;                                                  \
         const s16x8_ va = __builtin_shufflevector(fa[SET][i_][0], fa[SET][i_][1], 0, 1, 2, 3, 4, 5, 6, 7);        \
         const s16x8_ vb = __builtin_shufflevector(fb[SET][j_][0], fb[SET][j_][1], 0, 1, 2, 3, 4, 5, 6, 7);        \
         acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va),                      \
                                                               __builtin_bit_cast(bf16x8, vb), acc[i_][j_], 0, 0, 0); \
-    }
+    }                                                                                                              \
+    W16_PRIO(0);
     WG_STAMP_AT(1);
     if (nsteps > 0) issue_stage(0);
     if (NST == 3 && nsteps > 1) issue_stage(1);
@@ -627,6 +634,7 @@ __global__ __launch_bounds__(kThreads * G, NST == 3 ? 1 : 2) void conv_wgrad2_ke
             for (int b = 0; b < 2; ++b) { aA[a][b] += step; aB[a][b] += step; }
     }
 #undef W16_RD
+#undef W16_PRIO
 #undef W16_READ_A
 #undef W16_READ_B
 #undef W16_WAIT_A01B
