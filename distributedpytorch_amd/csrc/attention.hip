@@ -248,7 +248,9 @@ constexpr int kSLD = 96;                 // LDS bytes per dS row ([key][32 queri
 struct PamBwd {
     const bf16_raw* q; const bf16_raw* k; const bf16_raw* v; const bf16_raw* dy;
     const float* lse; const float* delta; const float* gamma;
-    float* dq;                  // [B, N, 64] fp32, zero-initialised (atomics)
+    float* dq;                  // [KB, B, N, 64] fp32 partials: key block kb STORES its share of dQ into slab kb (no
+                                //   atomics: plain stores run at 4-5x the float-atomic rate and the sum over the
+                                //   slabs, pam_dq_reduce_kernel, has a fixed order)
     bf16_raw* dk; bf16_raw* dv; // [B, N, 64], [B, N, DV]
     int B, N;
 };
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
     };
 
     const int nqb = (p.N + kBQB - 1) / kBQB;
+    float* __restrict__ dqp = p.dq + (long)blockIdx.x * p.B * p.N * kD;      // this key block's slab
     fetch(0);
     for (int qb = 0; qb < nqb; ++qb) {
         __syncthreads();                         // the previous step's reads of Ys / Qs / Ss are done
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qg = qrow0 + qt * 16 + 4 * g + r;
-                if (qg < p.N) atomicAdd(p.dq + (img + qg) * kD + wave * 16 + l15, dq[qt][r]);
+                if (qg < p.N) dqp[(img + qg) * kD + wave * 16 + l15] = dq[qt][r];
             }
     }
     // ---- epilogue: dV, dK through LDS (the V / K images are dead) as coalesced 16-byte row stores ----
@@ -480,7 +483,36 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(PamBwd p) {
     }
 }
 
-// delta'[row] = sum_c dy[row, c] o[row, c] (one wave per row of C = 512), dgamma += sum of all delta'
+// dq[i] (bf16) = sum over the KB slabs of part[kb][i], in slab order (bit-reproducible)
+__global__ __launch_bounds__(256) void pam_dq_reduce_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dq,
+                                                            long n8, int KB) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const float* src = part + i * 8;
+        for (int kb = 0; kb < KB; kb += 4) {                  // four slabs' loads in flight
+            float4 v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long off = (long)min(kb + u, KB - 1) * n8 * 8;
+                v[u][0] = *reinterpret_cast<const float4*>(src + off);
+                v[u][1] = *reinterpret_cast<const float4*>(src + off + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (kb + u < KB) {
+                    acc[0] += v[u][0].x; acc[1] += v[u][0].y; acc[2] += v[u][0].z; acc[3] += v[u][0].w;
+                    acc[4] += v[u][1].x; acc[5] += v[u][1].y; acc[6] += v[u][1].z; acc[7] += v[u][1].w;
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(dq + i * 8) = pack8(acc);
+    }
+}
+
+// delta'[row] = sum_c dy[row, c] o[row, c] (one wave per row of C = 512); dgamma_part[4 * block + wave] = that wave's
+// share of sum(delta') (the caller sums the gridDim.x * 4 partials: no atomics, fixed order)
 __global__ __launch_bounds__(256) void pam_delta_kernel(const bf16_raw* __restrict__ dy, const bf16_raw* __restrict__ o,
                                                         float* __restrict__ delta, float* __restrict__ dgamma,
                                                         long rows, int C) {
@@ -499,7 +531,7 @@ __global__ __launch_bounds__(256) void pam_delta_kernel(const bf16_raw* __restri
         if (lane == 0) delta[r] = acc;
         total += acc;
     }
-    if (dgamma && lane == 0) atomicAdd(dgamma, total);
+    if (dgamma && lane == 0) dgamma[blockIdx.x * 4 + wave] = total;
 }
 
 
@@ -602,7 +634,8 @@ __global__ __launch_bounds__(256) void cam_softmax_fwd_kernel(const float* __res
     }
 }
 
-// dE = -A (dA - sum_j dA_j A_j) with dA = gamma * graw (graw = dy^T X from cam_gram); dgamma += sum_j graw_j A_j.
+// dE = -A (dA - sum_j dA_j A_j) with dA = gamma * graw (graw = dy^T X from cam_gram); dgamma[row] = sum_j graw_j A_j
+// (per-row partials: the caller sums them).
 __global__ __launch_bounds__(256) void cam_softmax_bwd_kernel(const float* __restrict__ graw, const bf16_raw* __restrict__ a,
                                                               const float* __restrict__ gamma, float* __restrict__ de,
                                                               float* __restrict__ dgamma, long rows, int C) {
@@ -617,7 +650,7 @@ __global__ __launch_bounds__(256) void cam_softmax_bwd_kernel(const float* __res
         const float av = bf2f(a[row * C + c]);
         de[row * C + c] = -gam * av * (graw[row * C + c] - dot);
     }
-    if (dgamma && lane == 0) atomicAdd(dgamma, dot);
+    if (dgamma && lane == 0) dgamma[row] = dot;
 }
 
 // out[b][i][j] = alpha * in[b][i][j] + beta * in[b][j][i]  (C x C per image; bf16 out; fp32 or bf16 in)
@@ -654,14 +687,16 @@ DP_EXPORT int dp_pam_fwd(const void* q, const void* k, const void* v, const void
     return DP_LAUNCH_STATUS();
 }
 
-// dq fp32 [B, N, 64] must be zero on entry (atomics); dk bf16 [B, N, 64]; dv bf16 [B, N, 512]
+// dq_part: fp32 scratch [ceil(N / 64), B, N, 64] (every element is written); dq bf16 [B, N, 64]; dk bf16 [B, N, 64];
+// dv bf16 [B, N, 512]
 DP_EXPORT int dp_pam_bwd(const void* q, const void* k, const void* v, const void* dy, const float* lse,
-                         const float* delta, const float* gamma, float* dq, void* dk, void* dv, int B, int N, int D,
-                         int DV, hipStream_t st) {
-    if (D != kD || DV != kDVB || B <= 0 || N <= 0 || !q || !k || !v || !dy || !lse || !delta || !dq || !dk || !dv)
+                         const float* delta, const float* gamma, float* dq_part, void* dq, void* dk, void* dv, int B,
+                         int N, int D, int DV, hipStream_t st) {
+    if (D != kD || DV != kDVB || B <= 0 || N <= 0 || !q || !k || !v || !dy || !lse || !delta || !dq_part || !dq || !dk || !dv)
         return -1;
+    if (((uintptr_t)dq_part | (uintptr_t)dq) & 15) return -3;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dy | (uintptr_t)dk | (uintptr_t)dv) & 15) return -3;
-    PamBwd p{(const bf16_raw*)q, (const bf16_raw*)k, (const bf16_raw*)v, (const bf16_raw*)dy, lse, delta, gamma, dq,
+    PamBwd p{(const bf16_raw*)q, (const bf16_raw*)k, (const bf16_raw*)v, (const bf16_raw*)dy, lse, delta, gamma, dq_part,
              (bf16_raw*)dk, (bf16_raw*)dv, B, N};
     constexpr int lds = kBK * kWLD + kBK * kKLD + kBQB * kWLD + kBQB * kKLD + kBK * kSLD;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -670,11 +705,22 @@ DP_EXPORT int dp_pam_bwd(const void* q, const void* k, const void* v, const void
         (void)hipFuncSetAttribute((const void*)pam_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         once = true;
     }
-    hipLaunchKernelGGL(pam_bwd_kernel, dim3((N + kBK - 1) / kBK, B), dim3(256), lds, st, p);
+    const int KB = (N + kBK - 1) / kBK;
+    hipLaunchKernelGGL(pam_bwd_kernel, dim3(KB, B), dim3(256), lds, st, p);
+    const long n8 = (long)B * N * kD / 8;
+    const long rb = (n8 + 255) / 256;
+    hipLaunchKernelGGL(pam_dq_reduce_kernel, dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, st, dq_part,
+                       (bf16_raw*)dq, n8, KB);
     return DP_LAUNCH_STATUS();
 }
 
-// delta fp32 [rows]; dgamma fp32 [1] accumulated (may be null); C % 512 == 0
+// delta fp32 [rows]; dgamma fp32 [dp_pam_delta_parts(rows)] partial sums (may be null); C % 512 == 0
+DP_EXPORT long dp_pam_delta_parts(long rows) {
+    long blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    return blocks * 4;
+}
+
 DP_EXPORT int dp_pam_delta(const void* dy, const void* o, float* delta, float* dgamma, long rows, int C,
                            hipStream_t st) {
     if (rows <= 0 || C <= 0 || C % 512 != 0 || !dy || !o || !delta) return -1;
@@ -692,7 +738,7 @@ DP_EXPORT int dp_cam_gram(const void* u, const void* v, float* g, int B, int N, 
     const int steps = (N + kGP - 1) / kGP;
     const int tiles = (C / kGT) * (C / kGT);
     int splits = (1024 + tiles * B - 1) / (tiles * B);         // ~1024 workgroups in total
-    if (splits < 1) splits = 1;
+    if (splits < 1 || g_dp_deterministic) splits = 1;         // (deterministic: one writer per output element)
     if (splits > steps) splits = steps;
     const int sps = (steps + splits - 1) / splits;
     splits = (steps + sps - 1) / sps;

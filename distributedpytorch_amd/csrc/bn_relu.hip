@@ -463,6 +463,7 @@ inline dim3 grid_reduce(long M, int C) {
     const int slabs = (C8 + kReduceSlab - 1) / kReduceSlab;
     const int rpp = kThreads / kReduceSlab;
     long splits = (1024 + slabs - 1) / slabs;
+    if (g_dp_deterministic) splits = 1;          // one block per channel slab: its atomics have no second writer
     const long max_by_rows = (M + (long)rpp * 8 - 1) / ((long)rpp * 8);
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
@@ -556,15 +557,17 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restric
                                                           float* __restrict__ ds, int Cout, int Cin, float sink_scale) {
     __shared__ float part[4][64];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    const int k0 = blockIdx.y * 64;
     float acc = 0.f;
     if (j < Cin) {
         const float sj = s[j] * sink_scale;
-        for (int k = k0 + rl; k < min(k0 + 64, Cout); k += 4) {
-            const long idx = (long)k * Cin + j;
-            const float g = dwf[idx];
-            acc = fmaf(g, bf2f(w[idx]), acc);
-            dw_sink[idx] += g * sj;
+        // (gridDim.y = 1 in deterministic mode: one block walks all row tiles of its 64 columns)
+        for (int k0 = blockIdx.y * 64; k0 < Cout; k0 += gridDim.y * 64) {
+            for (int k = k0 + rl; k < min(k0 + 64, Cout); k += 4) {
+                const long idx = (long)k * Cin + j;
+                const float g = dwf[idx];
+                acc = fmaf(g, bf2f(w[idx]), acc);
+                dw_sink[idx] += g * sj;
+            }
         }
     }
     part[rl][threadIdx.x & 63] = acc;
@@ -770,7 +773,7 @@ DP_EXPORT int dp_bn_fold_bwd(const float* dwf, const void* w, const float* s, co
                              float* dgamma_sink, float count, float sink_scale, int Cout, int Cin, hipStream_t st) {
     if (!dwf || !w || !s || !rstd || !mean || !dw_sink || !ds || !cvec || !cshift || Cin <= 0 || Cout <= 0 || count <= 0.f)
         return -1;
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64), dim3(256), 0, st, dwf,
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((Cin + 63) / 64, g_dp_deterministic ? 1 : (Cout + 63) / 64), dim3(256), 0, st, dwf,
                        (const bf16_raw*)w, s, dw_sink, ds, Cout, Cin, sink_scale);
     hipLaunchKernelGGL(bn_fold_bwd_final_kernel, dim3((Cin + 255) / 256), dim3(256), 0, st, ds, gamma, rstd, mean, cvec,
                        cshift, dgamma_sink, 1.f / count, sink_scale, Cin);

@@ -48,5 +48,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Deterministic mode (ops._backend.set_deterministic / DPAMD_DETERMINISTIC=1; defined in misc.hip): launchers
+// whose blocks would add into a shared address with float atomics shape their grids so that every address has ONE
+// writer (row splits = 1, one replica per block, split-K = 1); the Python wrappers sum the replicas in a fixed
+// order.  Two identical launches are then bit-identical.  Host-side flag only: no kernel reads it.
+extern "C" int g_dp_deterministic;
+
 // Launch-status helper: launchers return hipGetLastError() as int (0 = ok).
 #define DP_LAUNCH_STATUS() ((int)hipGetLastError())

@@ -801,7 +801,7 @@ namespace {
 // set by dp_conv_igemm2b for the launch it forwards to dp_conv_igemm2r (host-side, same thread)
 thread_local const void* t_bnx = nullptr;
 thread_local const void* t_bna = nullptr;
-thread_local const void* t_bnmask = nullptr;   // set by dp_conv_set_bnmask for the next dp_conv_igemm2b
+thread_local const void* t_bnmask = nullptr;
 thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
@@ -895,24 +895,19 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     }
 }
 
-namespace { thread_local const void* t_bnmask_next = nullptr; }
-// The next dp_conv_igemm2b launch of this thread takes its ReLU mask from these positivity bits ([N*Ho*Wo, Cout/8]
-// bytes, written by the BatchNorm apply kernel) instead of from bna / a recomputation.
-DP_EXPORT int dp_conv_set_bnmask(const void* mask) { t_bnmask_next = mask; return 0; }
-
 // Data-gradient launch with the fused BN+ReLU backward prologue (see Conv2Args::bnx).  bnx / bna:
 // [N*Ho*Wo, Cout] bf16 (bna may be null: mask recomputed from bnx), bn_mean / bn_rstd / bn_w / bn_b:
-// fp32 [Cout] (bn_w, bn_b may be null), bnsums: fp32 [bn_reps, 2, Cout], zero-initialised.
+// fp32 [Cout] (bn_w, bn_b may be null), bnsums: fp32 [bn_reps, 2, Cout], zero-initialised.  bnmask (or null):
+// positivity bits of a ([N*Ho*Wo, Cout/8] bytes, written by the BatchNorm apply kernel) — the ReLU mask then comes
+// from them instead of from bna / a recomputation.
 DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
                               int Cout, int R, int S, int smul, int sdiv, int pad_h, int pad_w, int dil_h,
                               int dil_w, int cfg, const void* res, const void* bnx, const void* bna,
-                              const float* bn_mean, const float* bn_rstd, const float* bn_w, const float* bn_b,
-                              float* bnsums, int bn_reps, hipStream_t st) {
-    const void* mask_ = t_bnmask_next;      // armed state is consumed even if this call is rejected
-    t_bnmask_next = nullptr;
+                              const void* bnmask, const float* bn_mean, const float* bn_rstd, const float* bn_w,
+                              const float* bn_b, float* bnsums, int bn_reps, hipStream_t st) {
     if (!bnx || !bn_mean || !bn_rstd || !bnsums || bn_reps < 1) return -1;
     if (((uintptr_t)bnx | (uintptr_t)bna) & 15) return -3;
-    t_bnmask = mask_;
+    t_bnmask = bnmask;
     t_bnx = bnx; t_bna = bna; t_bnsums = bnsums; t_bn_reps = bn_reps;
     t_bnp[0] = bn_mean; t_bnp[1] = bn_rstd; t_bnp[2] = bn_w; t_bnp[3] = bn_b;
     const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,

@@ -116,75 +116,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16_raw* __
     }
 }
 
-// thread = (channel group, row lane); rows = output pixels; 9 taps × 8 channels of fp32 partials
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16_raw* __restrict__ dy,
-                                                                const bf16_raw* __restrict__ x,
-                                                                float* __restrict__ dw9, Dw p) {
-    __shared__ float smem[8 * 256];
-    const int C8 = p.C >> 3;
-    const int base = blockIdx.y * 256;
-    const int cgs = min(256, C8 - base);
-    const int rpp = 256 / cgs;
-    const int cgl = threadIdx.x % cgs, rlane = threadIdx.x / cgs;
-    const int cg = base + cgl;
-    const bool active = rlane < rpp;
-    float acc[9][8];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    const long P = (long)p.N * p.Ho * p.Wo;
-    if (active) {
-        for (long r = (long)blockIdx.x * rpp + rlane; r < P; r += (long)gridDim.x * rpp) {
-            const int ox = (int)(r % p.Wo);
-            const long t2 = r / p.Wo;
-            const int oy = (int)(t2 % p.Ho);
-            const int n = (int)(t2 / p.Ho);
-            float dv[8];
-            unpack8(*reinterpret_cast<const uint4*>(dy + r * p.C + cg * 8), dv);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int iy = oy * p.stride - p.pad_h + a * p.dil;
-                if ((unsigned)iy >= (unsigned)p.Hi) continue;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int ix = ox * p.stride - p.pad_w + q * p.dil;
-                    if ((unsigned)ix >= (unsigned)p.Wi) continue;
-                    float xv[8];
-                    unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * p.Hi + iy) * p.Wi + ix) * p.C + cg * 8), xv);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[a * 3 + q][j] = fmaf(dv[j], xv[j], acc[a * 3 + q][j]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) smem[j * 256 + threadIdx.x] = active ? acc[t][j] : 0.f;
-        __syncthreads();
-        if (rlane == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float s = 0.f;
-                for (int rl = 0; rl < rpp; ++rl) s += smem[j * 256 + rl * cgs + cgl];
-                atomicAdd(dw9 + t * p.C + cg * 8 + j, s);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Second generation: strip mapping.  The rocprofv3 trace of Xception-65 (profiles/
-// r1_native_x65_os8_b16.md) shows the kernels above 3-11x off the HBM time of their tensors
-// (bwd_weight 445 us for 197 MB): a grid-stride loop sends consecutive iterations of a thread to pixels
-// a thousand apart, so none of the 9 overlapping taps is ever found in the CU's L1, the 9 weight vectors
-// are re-loaded per pixel, and every element pays three integer divisions.  Here a thread owns ONE
-// channel group (8 channels) and a strip of kStrip CONSECUTIVE pixels: the weights (fwd / bwd_data) or
-// the 72 partial sums (bwd_weight) live in registers for the whole strip, the pixel coordinates advance
-// by increments, and the taps of neighbouring pixels hit in L1.  A block is 32 channel groups x 8
-// strips (a wave-instruction moves 2 x 512 contiguous bytes).
+// Strip-mapped weight gradient (the general-shape fallback: stride 2, dilations whose row ring does not fit the
+// LDS).  A thread owns ONE channel group (8 channels) and a strip of STRIP CONSECUTIVE output pixels: the 72
+// partial sums live in registers for the whole strip, the pixel coordinates advance by increments, and the taps
+// of neighbouring pixels hit in L1 (a grid-stride mapping spilled the partial sums per pixel: 445 us for 197 MB,
+// profiles/r1_native_x65_os8_b16.md).  A block is 32 channel groups x 8 strips.
+// `reps`: dw9 is [reps][9][C] and block b adds into replica b % reps (1 = everybody into one buffer; the
+// deterministic mode gives every block its own and sums them in a fixed order afterwards).
 constexpr int kSlab = 32;      // channel groups per block
 constexpr int kStrips = 8;     // strips per block (kSlab * kStrips = 256 threads)
 
@@ -202,84 +141,11 @@ __device__ __forceinline__ Strip make_strip(int C8, long P) {
 }
 
 template <int STRIP>
-__global__ __launch_bounds__(256) void dwconv2_fwd_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w9,
-                                                          bf16_raw* __restrict__ y, Dw p) {
-    const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Ho * p.Wo);
-    if (!s.active) return;
-    float w[9][8];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) unpack8(*reinterpret_cast<const uint4*>(w9 + t * p.C + s.cg * 8), w[t]);
-    int ox = (int)(s.p0 % p.Wo);
-    long t2 = s.p0 / p.Wo;
-    int oy = (int)(t2 % p.Ho);
-    int n = (int)(t2 / p.Ho);
-    for (long r = s.p0; r < s.p1; ++r) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        const bf16_raw* xn = x + (long)n * p.Hi * p.Wi * p.C + s.cg * 8;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int iy = oy * p.stride - p.pad_h + a * p.dil;
-            if ((unsigned)iy >= (unsigned)p.Hi) continue;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int ix = ox * p.stride - p.pad_w + q * p.dil;
-                if ((unsigned)ix >= (unsigned)p.Wi) continue;
-                float xv[8];
-                unpack8(*reinterpret_cast<const uint4*>(xn + ((long)iy * p.Wi + ix) * p.C), xv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[a * 3 + q][j], acc[j]);
-            }
-        }
-        *reinterpret_cast<uint4*>(y + r * p.C + s.cg * 8) = pack8(acc);
-        if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++n; } }
-    }
-}
-
-// stride 1 only: dx[iy, ix] = Σ_t dy[iy + pad - a·dil, ix + pad - q·dil] · w[t]
-template <int STRIP>
-__global__ __launch_bounds__(256) void dwconv2_bwd_data_kernel(const bf16_raw* __restrict__ dy,
-                                                               const bf16_raw* __restrict__ w9,
-                                                               bf16_raw* __restrict__ dx, Dw p) {
-    const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Hi * p.Wi);
-    if (!s.active) return;
-    float w[9][8];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) unpack8(*reinterpret_cast<const uint4*>(w9 + t * p.C + s.cg * 8), w[t]);
-    int ix = (int)(s.p0 % p.Wi);
-    long t2 = s.p0 / p.Wi;
-    int iy = (int)(t2 % p.Hi);
-    int n = (int)(t2 / p.Hi);
-    for (long r = s.p0; r < s.p1; ++r) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        const bf16_raw* dn = dy + (long)n * p.Ho * p.Wo * p.C + s.cg * 8;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int oy = iy + p.pad_h - a * p.dil;
-            if ((unsigned)oy >= (unsigned)p.Ho) continue;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int ox = ix + p.pad_w - q * p.dil;
-                if ((unsigned)ox >= (unsigned)p.Wo) continue;
-                float dv[8];
-                unpack8(*reinterpret_cast<const uint4*>(dn + ((long)oy * p.Wo + ox) * p.C), dv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(dv[j], w[a * 3 + q][j], acc[j]);
-            }
-        }
-        *reinterpret_cast<uint4*>(dx + r * p.C + s.cg * 8) = pack8(acc);
-        if (++ix == p.Wi) { ix = 0; if (++iy == p.Hi) { iy = 0; ++n; } }
-    }
-}
-
-template <int STRIP>
 __global__ __launch_bounds__(256) void dwconv2_bwd_weight_kernel(const bf16_raw* __restrict__ dy,
                                                                  const bf16_raw* __restrict__ x,
-                                                                 float* __restrict__ dw9, Dw p) {
+                                                                 float* __restrict__ dw9, Dw p, int reps) {
     __shared__ float red[kStrips][kSlab][9];       // one channel of the 8 at a time
+    dw9 += (long)(blockIdx.x % (unsigned)reps) * 9 * p.C;
     const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Ho * p.Wo);
     float acc[9][8];
 #pragma unroll
@@ -332,228 +198,12 @@ __global__ __launch_bounds__(256) void dwconv2_bwd_weight_kernel(const bf16_raw*
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Third generation: LDS row tiles (stride 1, "same" padding: pad == dil — every Xception middle/exit
-// unit).  Both mappings above leave the 9x reuse of an input element to the caches: with dilation d the
-// three tap rows of a pixel are 2d image rows apart (d = 2, 728 channels, 65 columns: 376 KB), far beyond
-// L1, so every tap is an L2 request — 8 TB/s of L2 traffic for a 100 MB tensor, 2.5x (fwd) to 8x (wgrad)
-// off the HBM time (profiles/r1_native_x65_os8_b16_v2.md).  Here a block stages TH + 2d FULL-WIDTH image
-// rows x 64 channels in LDS once (global reads: (TH + 2d) / TH of the tensor, 128 contiguous bytes per
-// pixel), and all taps are conflict-free ds_read_b128: a wave reads 8 neighbouring pixels x 8 channel
-// groups = 1 KiB contiguous.
-//   MODE 0: out = depthwise conv of `in` (forward; data gradient = the same with the taps flipped)
-//   MODE 2: dw[t][c] += sum over the tile of in2 (dy) x tap t of `in` (x): 72 partial sums per thread,
-//           block combine through the (by then free) LDS tile, one atomic per (tap, channel) and block.
-struct Dw3 {
-    const bf16_raw* in; const bf16_raw* in2; const bf16_raw* w9; void* out;
-    int N, C, H, W, dil, TH, tiles_h, flip;
-    unsigned in_bytes;
-    float* stats;           // MODE 0: optional [stat_reps][2][C] per-channel sums of out and out^2 (BatchNorm
-    int stat_reps;          //   batch statistics for free, as in the dense kernels' epilogue)
-};
-
 constexpr unsigned kOOBd = 0x80000000u;
-constexpr int kDw3MaxPx = 12;          // MODE 2: pixels per thread whose dy is pre-loaded into registers
-
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void dwconv3_kernel(Dw3 p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    // [rows + 2d][W + 2d][8] 16-byte chunks: the horizontal padding is physically present (zeros), so the
-    // nine taps of a pixel are nine FIXED offsets from its own chunk — no bounds tests in the tap loop
-    const uint4* tile = reinterpret_cast<const uint4*>(smem3);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.y * 64;
-    const int ncg = min(8, (p.C - c0) >> 3);
-    const int n = blockIdx.x / p.tiles_h, th = blockIdx.x - n * p.tiles_h;
-    const int y0 = th * p.TH;
-    const int rows = min(p.TH, p.H - y0);
-    const int d = p.dil;
-    const int R = rows + 2 * d;
-    const int Wt = p.W + 2 * d;
-    const int cg = tid & 7, pl = tid >> 3;
-    const bool cg_ok = cg < ncg;
-    const int npix = rows * p.W;
-
-    // MODE 2: this thread's dy vectors go to registers first — their latency hides under the staging
-    uint4 dq[kDw3MaxPx];
-    if (MODE == 2) {
-#pragma unroll
-        for (int k = 0; k < kDw3MaxPx; ++k) {
-            const int pi = pl + 32 * k;
-            dq[k] = make_uint4(0, 0, 0, 0);
-            if (cg_ok && pi < npix)
-                dq[k] = *reinterpret_cast<const uint4*>(p.in2 + ((long)n * p.H * p.W + (long)y0 * p.W + pi) * p.C + c0 + cg * 8);
-        }
-    }
-    // ---- stage through LDS-DMA: one wave-instruction = 8 pixels x 128 bytes = 1 KiB, linear in LDS.
-    // Rows outside the image, channel groups beyond C and the tail pixels get an out-of-range offset:
-    // the buffer range check writes zeros.
-    {
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-        const int c8 = lane & 7;
-        const int npx = R * Wt;
-        const unsigned img = (unsigned)(((long)n * p.H * p.W * p.C + c0 + c8 * 8) * 2);
-        for (int q0 = wave * 8; q0 < npx; q0 += 32) {
-            const int q = q0 + (lane >> 3);
-            const int r = q / Wt, px = q - r * Wt - d;
-            const int iy = y0 - d + r;
-            const bool ok = (c8 < ncg) & (q < npx) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W);
-            const unsigned off = img + (unsigned)((iy * p.W + px) * p.C * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem3 + q0 * 128), 16,
-                                                     ok ? off : kOOBd, 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (MODE == 0) {
-        float w[9][8];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (cg_ok) unpack8(*reinterpret_cast<const uint4*>(p.w9 + (p.flip ? 8 - t : t) * p.C + c0 + cg * 8), w[t]);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) w[t][j] = 0.f;
-            }
-        }
-        bf16_raw* out = reinterpret_cast<bf16_raw*>(p.out) + ((long)n * p.H + y0) * p.W * p.C + c0 + cg * 8;
-        int toff[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) toff[a * 3 + q] = (a * d * Wt + q * d) * 8;
-        float s1[8], s2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-        int y = pl / p.W, x = pl - y * p.W;             // pl < 32: at most a few rows down
-        for (int pi = pl; pi < npix; pi += 32) {
-            const uint4* t0 = tile + (y * Wt + x) * 8 + cg;
-            float acc[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float xv[8];
-                unpack8(t0[toff[t]], xv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], w[t][j], acc[j]);
-            }
-            if (cg_ok) *reinterpret_cast<uint4*>(out + (long)pi * p.C) = pack8(acc);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
-            x += 32;
-            while (x >= p.W) { x -= p.W; ++y; }
-        }
-        if (p.stats) {                                   // uniform
-            __syncthreads();                             // everyone is done with the tile
-            float* red = reinterpret_cast<float*>(smem3);       // [32 pixel lanes][8 cg][16]
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(pl * 8 + cg) * 16 + j] = s1[j];
-                red[(pl * 8 + cg) * 16 + 8 + j] = s2[j];
-            }
-            __syncthreads();
-            if (tid < 128) {
-                const int g = tid >> 4, e = tid & 15;
-                if (g < ncg) {
-                    float v = 0.f;
-#pragma unroll 8
-                    for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 16 + e];
-                    float* dst = p.stats + (long)(blockIdx.x % p.stat_reps) * 2 * p.C;
-                    atomicAdd(dst + (e >> 3) * p.C + c0 + g * 8 + (e & 7), v);
-                }
-            }
-        }
-    } else {
-        float acc[9][8];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-        int toff[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) toff[a * 3 + q] = (a * d * Wt + q * d) * 8;
-        int y = pl / p.W, x = pl - y * p.W;
-#pragma unroll
-        for (int k = 0; k < kDw3MaxPx; ++k) {
-            const int pi = pl + 32 * k;
-            if (pi < npix) {
-                const uint4* t0 = tile + (y * Wt + x) * 8 + cg;
-                float dv[8];
-                unpack8(dq[k], dv);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    float xv[8];
-                    unpack8(t0[toff[t]], xv);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(dv[j], xv[j], acc[t][j]);
-                }
-            }
-            x += 32;
-            while (x >= p.W) { x -= p.W; ++y; }
-        }
-        // ---- block combine: red[pixel lane][cg][72] over the tile's LDS (the launch allocates >= 73,728 B)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem3);
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) red[(pl * 8 + cg) * 72 + t * 8 + j] = acc[t][j];
-        __syncthreads();
-        float* dw = reinterpret_cast<float*>(p.out);
-        for (int o = tid; o < 8 * 72; o += 256) {
-            const int g = o / 72, e = o - g * 72;
-            if (g >= ncg) continue;
-            float v = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 72 + e];
-            const int t = e >> 3, j = e & 7;
-            atomicAdd(dw + t * p.C + c0 + g * 8 + j, v);
-        }
-    }
-}
-
-// rows per tile, 0 = shape not taken (then the older kernels run).  Two blocks per CU when the tile fits
-// in 80 KiB (one block stages while the other computes), else one block of up to 150 KiB.
-inline int dw3_rows(int H, int W, int dil, bool wgrad) {
-    const long row_bytes = (long)(W + 2 * dil) * 128;
-    long th = (80 * 1024 - 1024) / row_bytes - 2 * dil;
-    if (th < 1 || th < dil) th = (150 * 1024) / row_bytes - 2 * dil;
-    if (th > H) th = H;
-    if (wgrad && th * W > 32 * kDw3MaxPx) th = (32 * kDw3MaxPx) / W;
-    if (th < 1) return 0;
-    return (int)th;
-}
-
-template <int MODE>
-inline int launch_dw3(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
-                      int flip, int TH, hipStream_t st, float* stats = nullptr, int stat_reps = 1) {
-    const long in_bytes = (long)N * H * W * C * 2;
-    if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
-    Dw3 p{(const bf16_raw*)in, (const bf16_raw*)in2, (const bf16_raw*)w9, out, N, C, H, W, dil, TH, (H + TH - 1) / TH, flip,
-          (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps};
-    const long nb = (long)N * p.tiles_h;
-    if (nb > 0x7fffffffL) return -4;
-    int lds = (TH + 2 * dil) * (W + 2 * dil) * 128 + 1024;      // + one wave-instruction of slack for the tail
-    if (MODE == 2 && lds < 32 * 8 * 72 * 4) lds = 32 * 8 * 72 * 4;
-    if (MODE == 0 && stats && lds < 32 * 8 * 16 * 4) lds = 32 * 8 * 16 * 4;
-    if (lds > 160 * 1024) return -2;
-    auto kfn = dwconv3_kernel<MODE>;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nb, (unsigned)((C + 63) / 64)), dim3(256), lds, st, p);
-    return DP_LAUNCH_STATUS();
-}
-
 // ------------------------------------------------------------------------------------------------
-// Fourth generation: rolling row window.  The row tiles above re-read their 2d halo rows per tile (TH = 4 at
-// d = 2 on the 65-column maps: every element staged TWICE) and a block alternates "wait for the whole tile" /
-// "compute" with nothing in flight while it computes: 427 us for a 394 MB tensor, 2.7x its HBM time
-// (profiles/r2_x65_os8_b64_v29_profile.md).  Here a block walks DOWN one image (or one of `hsplit` horizontal
+// Rolling row window (stride 1, "same" padding: every Xception middle / exit unit).  LDS row TILES (the generation
+// before this one, removed) re-read their 2d halo rows per tile (TH = 4 at d = 2 on the 65-column maps: every element
+// staged TWICE) and alternated "wait for the whole tile" / "compute" with nothing in flight while computing: 427 us
+// for a 394 MB tensor, 2.7x its HBM time (profiles/r2_x65_os8_b64_v29_profile.md).  Here a block walks DOWN one image (or one of `hsplit` horizontal
 // bands) for a 64-channel slab with a ring of NR = 2 TS + 2d rows in LDS: TS + 2d rows feed the TS output rows
 // of the current step while LDS-DMA brings the next TS rows in, so every element is fetched once (plus 2d rows
 // per band) and the fetch overlaps the arithmetic.  Ring rows are rowpx = ceil8(W + 2d) pixels wide so one
@@ -989,7 +639,8 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) red[(pl * 8 + cg) * 72 + t * 8 + j] = acc2[t][j];
         __syncthreads();
-        float* dw = reinterpret_cast<float*>(p.out);
+        // (stat_reps doubles as the replica count of the [reps][9][C] weight-gradient buffer)
+        float* dw = reinterpret_cast<float*>(p.out) + (long)(bxi % p.stat_reps) * 9 * p.C;
         for (int o = tid; o < 8 * 72; o += 256) {
             const int g = o / 72, e = o - g * 72;
             if (g >= ncg) continue;
@@ -1059,439 +710,31 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
     return DP_LAUNCH_STATUS();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fifth generation, weight gradient on the MATRIX cores.  dw[t][c] = sum_p dy[p][c] * x[p + t][c] is, for a group
-// of 16 channels and one tap, the DIAGONAL of the 16x16 product  D[c][c'] = sum_p dy[p][c] * x[p + t][c']  — a GEMM
-// over the pixel index.  15/16 of the MFMA work is thrown away and it is still ~5x cheaper than the packed dot
-// products of dwconv4 MODE 2 (9 x v_mfma_f32_16x16x16_bf16 = 72 cycles per 16 pixels x 16 channels against 72
-// v_perm + 72 v_dot2c for the same), which leaves the kernel where a reduction over two tensors belongs: on the
-// HBM stream (dwconv4 MODE 2: 606 us per 728-channel 65x65 layer at batch 64 for 788 MB).
-//   * x walks through the same rolling row ring as dwconv4; dy gets a ring of its own (2 TS rows) with the SAME row
-//     geometry (rowpx pixels, d columns of physical zero padding on the left), so one pixel index addresses both.
-//   * both operands are pixel-major in LDS ([pixel][64 channels], as they lie in memory) and are needed
-//     channel-major by the MFMA: ds_read_b64_tr_b16 delivers 4 pixels of one channel per lane.  16-byte chunks are
-//     XOR-swizzled by (pixel & 7) through the DMA's SOURCE address (the destination stays lane-linear), which makes
-//     the transposed reads of 8 consecutive pixels conflict-free.
-//   * a row is cut into 16-pixel K chunks; the last chunk of a row whose width is 8 mod 16 overlaps its
-//     predecessor by 8 pixels and zeroes those in the dy fragment.  Padding columns hold dy = 0, so x may be
-//     anything finite there (guard bands before / after the rings are zeroed once).
-//   * 8 waves: wave & 3 = the 16-channel group of the 64-channel slab, wave >> 2 = which of the TS = 2 rows of a step.
-// MEASURED (gpurun_out/ak, 728 channels, 65x65, batch 64, launchers timed alone): 318 us against 222 us for dwconv4
-// MODE 2 — which in isolation already runs at 3.55 TB/s; its 606 us in the training step is the low-priority
-// auxiliary stream sharing the chip, not arithmetic.  The two rings (x and dy) take 112 KiB, so ONE block per CU,
-// and a block that alternates "wait for the rows" / "read + MFMA" has nothing else on its CU to fill the waits:
-// 2.5 TB/s.  Kept selectable (DPAMD_DWCONV_GEN=5) and tested; not the default.
-typedef short s16x4d __attribute__((ext_vector_type(4)));
-typedef float f32x4d __attribute__((ext_vector_type(4)));
 
-struct Dw5W {
-    const bf16_raw* x; const bf16_raw* dy; float* dw;
-    int N, C, H, W, dil, NR, hsplit, rows_split, rowpx;
-    unsigned bytes;
-};
+// rolling-window kernels on (default) / off (tests: the flat kernels on the same shapes)
+static int kDwWindow = 1;
 
-__global__ __launch_bounds__(512) void dwconv5_wgrad_kernel(Dw5W p) {
-    constexpr int TS = 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cgw = wave & 3, rs = wave >> 2;
-    const int c0 = blockIdx.y * 64;
-    const int ncg = min(8, (p.C - c0) >> 3);
-    const int n = blockIdx.x / p.hsplit, hs = blockIdx.x - n * p.hsplit;
-    const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
-    const int d = p.dil, W = p.W, NR = p.NR;
-    const int rowb = p.rowpx * 128, ipr = p.rowpx >> 3;
-    unsigned char* xring = smem5 + 1024;
-    unsigned char* dring = xring + NR * rowb;
-    // Reads of x run up to d pixels past either end of a ring row (against dy = 0): everything they can reach — the
-    // guard bands, and ring slots no DMA has filled yet — must hold FINITE values, so the whole allocation is
-    // zeroed once (a block lives for a whole image band).
-    for (int i = tid * 16; i < 2048 + (NR + 2 * TS) * rowb; i += 512 * 16)
-        *reinterpret_cast<uint4*>(smem5 + i) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.bytes, 0x00020000);
-    const int c8s = (lane & 7) ^ (lane >> 3);          // logical 16-byte chunk this lane fetches into slot lane & 7
-    const unsigned img = (unsigned)(((long)n * p.H * W * p.C + c0 + c8s * 8) * 2);
-    auto stage = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned char* ring, int r_first, int nrows, int row0, int nslots) {
-        for (int i = wave; i < nrows * ipr; i += 8) {
-            const int rr = i / ipr, seg = i - rr * ipr;
-            const int iy = r_first + rr;
-            const int slot = (iy - row0) % nslots;
-            const int px = seg * 8 + (lane >> 3) - d;
-            const bool ok = (c8s < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)W);
-            const unsigned off = img + (unsigned)((iy * W + px) * p.C * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(ring + (long)slot * rowb + seg * 1024), 16,
-                ok ? off : kOOBd, 0, 0, 0);
-        }
-    };
-    // transposed-read geometry: lane 4q + pp of 16-lane group gq supplies pixel 4 gq + q, channels 4 pp .. 4 pp + 3
-    const int gq = lane >> 4, tl = lane & 15, q = tl >> 2, pp = tl & 3;
-    const int kpix = 4 * gq + q;
-    const int chunk = 2 * cgw + (pp >> 1);
-    const unsigned lane_dy = (unsigned)(kpix * 128 + ((chunk ^ (kpix & 7)) << 4) + ((pp & 1) << 3));
-    unsigned lane_x[3];
-#pragma unroll
-    for (int s2 = 0; s2 < 3; ++s2)
-        lane_x[s2] = (unsigned)(kpix * 128 + ((chunk ^ ((kpix + (s2 - 1) * d) & 7)) << 4) + ((pp & 1) << 3));
-    f32x4d acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4d{0.f, 0.f, 0.f, 0.f};
-    const int nch = (p.rowpx + 15) >> 4;
-
-    stage(rx, xring, ya - d, TS + 2 * d, ya - d, NR);
-    stage(rd, dring, ya, TS, ya, 2 * TS);
-    for (int y0 = ya; y0 < yb; y0 += TS) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();          // this step's rows have landed; everyone is done with the rows about to be replaced
-        if (y0 + TS < yb) {
-            stage(rx, xring, y0 + TS + d, TS, ya - d, NR);
-            stage(rd, dring, y0 + TS, TS, ya, 2 * TS);
-        }
-        const int y = y0 + rs;
-        if (y < yb) {                                        // wave-uniform: EXEC stays full for the transposed reads
-            const unsigned char* drow = dring + ((y - ya) % (2 * TS)) * rowb;
-            const unsigned char* xrow[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) xrow[r] = xring + ((y - ya + r * d) % NR) * rowb;
-            for (int ch = 0; ch < nch; ++ch) {
-                int px0 = ch * 16;
-                const bool overlap = px0 + 16 > p.rowpx;     // uniform
-                if (overlap) px0 = p.rowpx - 16;
-                s16x4d a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4d*)(drow + px0 * 128 + lane_dy));
-                if (overlap && lane < 32) a = s16x4d{0, 0, 0, 0};      // pixels the previous chunk already took
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int s2 = 0; s2 < 3; ++s2) {
-                        const s16x4d b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4d*)(xrow[r] + (px0 + (s2 - 1) * d) * 128 + lane_x[s2]));
-                        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[r * 3 + s2], 0, 0, 0);
-                    }
-            }
-        }
-    }
-    // the diagonal: lane (gq, tl) holds D[4 gq + j][tl] in register j, so channel tl sits in the lanes with tl >> 2 == gq
-    if ((tl >> 2) == gq) {
-        const int c = c0 + 16 * cgw + tl;
-        if (c < p.C) {
-            const int j = tl & 3;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float v = j == 0 ? acc[t][0] : (j == 1 ? acc[t][1] : (j == 2 ? acc[t][2] : acc[t][3]));
-                atomicAdd(p.dw + t * p.C + c, v);
-            }
-        }
-    }
+inline bool dw_same(int stride, int pad_h, int pad_w, int dil, int Hi, int Wi, int Ho, int Wo) {
+    return kDwWindow && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi;
 }
-
-inline int launch_dw5w(const void* x, const void* dy, void* dw, int N, int C, int H, int W, int dil, hipStream_t st) {
-    constexpr int TS = 2;
-    const long bytes = (long)N * H * W * C * 2;
-    if (bytes >= (1L << 31) - (1L << 24) || H < TS) return -2;
-    const int rowpx = (W + 2 * dil + 7) / 8 * 8;
-    if (rowpx < 16) return -2;
-    const int NR = 2 * TS + 2 * dil;
-    const long lds = 2048 + (long)(NR + 2 * TS) * rowpx * 128;
-    if (lds > 160 * 1024) return -2;
-    const long slabs = (C + 63) / 64, slots = 256;
-    int best_hs = 1;
-    long best_cost = -1;
-    for (int hs = 1; hs <= 4; ++hs) {
-        const int rows = (H + hs - 1) / hs;
-        if (hs > 1 && rows < 4 * TS) break;
-        const long bands = (H + rows - 1) / rows;
-        const long rounds = (N * slabs * bands + slots - 1) / slots;
-        const long cost = rounds * (rows + 2 * dil);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_hs = hs; }
-    }
-    const int rows_split = ((H + best_hs - 1) / best_hs + TS - 1) / TS * TS;     // bands start on a step boundary
-    const int hsplit = (H + rows_split - 1) / rows_split;
-    const long nb = (long)N * hsplit;
-    if (nb > 0x7fffffffL) return -4;
-    Dw5W p{(const bf16_raw*)x, (const bf16_raw*)dy, (float*)dw, N, C, H, W, dil, NR, hsplit, rows_split, rowpx,
-           (unsigned)bytes};
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute((const void*)dwconv5_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
-    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3((unsigned)nb, (unsigned)slabs), dim3(512), (size_t)lds, st, p);
-    return DP_LAUNCH_STATUS();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Generation 6: forward / data gradient on the MATRIX cores, same rolling row ring and two blocks per CU as
-// generation 4.  For a group of 16 channels the depthwise sum  out[p][c] = sum_t w[t][c] x[p + t][c]  is the dense
-// product  D[c][p] = sum_(t, c') A[c][(t, c')] B[(t, c')][p]  with the DIAGONAL weight matrix
-// A[c][(t, c')] = w[t][c] [c' == c]  and  B[(t, c')][p] = x[p + t][c'] : K = 9 taps x 16 channels = 144 (+16 of
-// padding) = 5 x v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels, 80 MFMA cycles for 256 outputs against ~115
-// VALU instructions per 8 outputs of a lane in dwconv4 (which is VALU-bound: 295 us for a 728-channel 65x65 layer at
-// batch 64, 2.7 TB/s).
-//   * B fragment of lane (pixel j = lane & 15, g = lane >> 4) for MFMA m: the 8 channels (g & 1) * 8 .. + 7 of the
-//     wave's 16-channel group at pixel x0 + j shifted by tap 2 m + (g >> 1): ONE ds_read_b128 from the ring.  The
-//     16-byte chunks of a pixel are XOR-swizzled by (pixel & 7) through the DMA's source address, which makes the 16
-//     lanes x 2 chunk columns of a read group hit 16 different bank quads.
-//   * A fragments (5 x 4 VGPRs per wave) are built once: one nonzero bf16 per lane.
-//   * wave = 16-channel group of the 64-channel slab; a lane ends up with 4 consecutive channels of one pixel
-//     (8-byte stores; the four waves of a block complete a pixel's 128 bytes).
-//   MODE 0: out = conv (+ BatchNorm statistics of out); MODE 1: data gradient with the skip gradient and the previous
-//   BatchNorm+ReLU's backward prologue, as dwconv4 MODE 1 (see Dw4).
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void dwconv6_kernel(Dw4 p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-    typedef __attribute__((ext_vector_type(4))) float f32x4w;
-    typedef __attribute__((ext_vector_type(4))) int i32x4w;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bxi, byi;
-    dw_block_coords(p.N * p.hsplit, (p.C + 63) >> 6, p.C, bxi, byi);
-    const int c0 = byi * 64;
-    const int ncg = min(8, (p.C - c0) >> 3);
-    const int n = bxi / p.hsplit, hs = bxi - n * p.hsplit;
-    const int ya = hs * p.rows_split, yb = min(p.H, ya + p.rows_split);
-    const int d = p.dil, W = p.W, TS = p.TS, NR = p.NR;
-    const int ipr = p.rowpx >> 3;        // wave-instructions per staged row
-    const int rowb = p.rowpx * 128;      // bytes per ring row
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-    const int c8s = (lane & 7) ^ (lane >> 3);          // logical 16-byte chunk this lane fetches into slot lane & 7
-    const unsigned img = (unsigned)(((long)n * p.H * W * p.C + c0 + c8s * 8) * 2);
-    auto stage = [&](int r_first, int nrows) {
-        for (int i = wave; i < nrows * ipr; i += 4) {
-            const int rr = i / ipr, seg = i - rr * ipr;
-            const int iy = r_first + rr;
-            const int slot = (iy - (ya - d)) % NR;
-            const int px = seg * 8 + (lane >> 3) - d;
-            const bool ok = (c8s < ncg) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)W);
-            const unsigned off = img + (unsigned)((iy * W + px) * p.C * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(smem6 + (long)slot * rowb + seg * 1024), 16,
-                ok ? off : kOOBd, 0, 0, 0);
-        }
-    };
-    // ---- lane geometry ----
-    const int j = lane & 15, g = lane >> 4;
-    const int cw = c0 + 16 * wave;                        // first channel of this wave's group
-    const int chunk = 2 * wave + (g & 1);                 // logical 16-byte chunk of the B fragment
-    // A fragments: lane (i = j, g) holds A[i][k = 8 g + e]; nonzero only at e = i & 7 when (i >> 3) == (g & 1)
-    i32x4w afr[5];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-        const int tap = 2 * m + (g >> 1);
-        unsigned wv = 0;
-        if (tap < 9 && (j >> 3) == (g & 1) && cw + j < p.C)
-            wv = (unsigned)p.w9[(p.flip ? 8 - tap : tap) * p.C + cw + j];
-        wv <<= 16 * (j & 1);
-        const int dd = (j & 7) >> 1;
-        afr[m] = i32x4w{dd == 0 ? (int)wv : 0, dd == 1 ? (int)wv : 0, dd == 2 ? (int)wv : 0, dd == 3 ? (int)wv : 0};
-    }
-    // B read offsets inside a ring row, per MFMA: pixel shift (s - 1) d and row r of tap 2 m + (g >> 1) (tap 9 = tap 8
-    // again: its weights are zero); the swizzle term depends on (j + shift) & 7 only (x0 is a multiple of 16)
-    int brow[5];                                          // tap row 0 / 1 / 2 of MFMA m's fragment
-    unsigned boff[5];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-        int tap = 2 * m + (g >> 1);
-        tap = tap > 8 ? 8 : tap;
-        const int r = tap / 3, s2 = tap - 3 * r;
-        brow[m] = r;
-        const int px = j + s2 * d;                        // ring pixel (left padding d) of output pixel j, tap column s2
-        boff[m] = (unsigned)(px * 128 + ((chunk ^ (px & 7)) << 4));
-    }
-    // per-lane channel quad (4 consecutive channels cq .. cq + 3 of pixel j)
-    const int cq = cw + 4 * g;
-    const bool cq_ok = cq < p.C;                          // C % 8 == 0 and cq % 4 == 0: a quad is valid as a whole ... or not
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f};
-    float mu[4], is[4], msc[4], msh[4];
-    if (MODE == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool on = cq_ok && p.bnx;
-            mu[e] = on ? p.bn_mean[cq + e] : 0.f;
-            is[e] = on ? p.bn_rstd[cq + e] : 0.f;
-            msc[e] = (on && p.bn_w ? p.bn_w[cq + e] : 1.f) * is[e];
-            msh[e] = fmaf(-mu[e], msc[e], on && p.bn_b ? p.bn_b[cq + e] : 0.f);
-        }
-    }
-    const int nseg = (W + 15) >> 4;
-    bf16_raw* outp = reinterpret_cast<bf16_raw*>(p.out);
-    const long img_px = (long)n * p.H * W;
-
-    stage(ya - d, TS + 2 * d);
-    for (int y0 = ya; y0 < yb; y0 += TS) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();          // this step's rows have landed; everyone is done with the rows about to be replaced
-        if (y0 + TS < yb) stage(y0 + TS + d, TS);
-        const int nrow = min(TS, yb - y0);
-        for (int ry = 0; ry < nrow; ++ry) {
-            const int rb = (y0 - ya) + ry;                 // ring row index (mod NR) of tap row 0
-            const int sl0 = (rb % NR) * rowb, sl1 = ((rb + d) % NR) * rowb, sl2 = ((rb + 2 * d) % NR) * rowb;   // uniform
-            unsigned badr[5];
-#pragma unroll
-            for (int m = 0; m < 5; ++m) badr[m] = (unsigned)(brow[m] == 0 ? sl0 : (brow[m] == 1 ? sl1 : sl2)) + boff[m];
-            for (int sg = 0; sg < nseg; ++sg) {
-                const int x0 = sg * 16;
-                f32x4w acc = f32x4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int m = 0; m < 5; ++m) {
-                    const i32x4w b = *reinterpret_cast<const i32x4w*>(smem6 + x0 * 128 + badr[m]);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[m]),
-                                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-                }
-                const int x = x0 + j;
-                const bool ok = cq_ok && x < W;
-                const long e0 = (img_px + (long)(y0 + ry) * W + x) * p.C + cq;
-                float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-                if (MODE == 0) {
-                    if (ok) {
-                        uint2 o;
-                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(outp + e0) = o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2a[e] = fmaf(v[e], v[e], s2a[e]); }
-                    }
-                } else if (ok) {
-                    if (p.res) {
-                        const uint2 r2 = *reinterpret_cast<const uint2*>(p.res + e0);
-                        v[0] += bf2f((bf16_raw)(r2.x & 0xffffu)); v[1] += bf2f((bf16_raw)(r2.x >> 16));
-                        v[2] += bf2f((bf16_raw)(r2.y & 0xffffu)); v[3] += bf2f((bf16_raw)(r2.y >> 16));
-                    }
-                    if (p.bnx) {
-                        const uint2 x2 = *reinterpret_cast<const uint2*>(p.bnx + e0);
-                        const float xv[4] = {bf2f((bf16_raw)(x2.x & 0xffffu)), bf2f((bf16_raw)(x2.x >> 16)),
-                                             bf2f((bf16_raw)(x2.y & 0xffffu)), bf2f((bf16_raw)(x2.y >> 16))};
-                        float av[4];
-                        if (p.bna) {
-                            const uint2 a2 = *reinterpret_cast<const uint2*>(p.bna + e0);
-                            av[0] = bf2f((bf16_raw)(a2.x & 0xffffu)); av[1] = bf2f((bf16_raw)(a2.x >> 16));
-                            av[2] = bf2f((bf16_raw)(a2.y & 0xffffu)); av[3] = bf2f((bf16_raw)(a2.y >> 16));
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) av[e] = fmaf(xv[e], msc[e], msh[e]);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = av[e] > 0.f ? v[e] : 0.f;
-                        uint2 o;
-                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(outp + e0) = o;
-                        // reduce exactly what BN backward will read back (bf16-rounded)
-                        const float rv[4] = {bf2f((bf16_raw)(o.x & 0xffffu)), bf2f((bf16_raw)(o.x >> 16)),
-                                             bf2f((bf16_raw)(o.y & 0xffffu)), bf2f((bf16_raw)(o.y >> 16))};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1[e] += rv[e]; s2a[e] = fmaf(rv[e], (xv[e] - mu[e]) * is[e], s2a[e]); }
-                    } else {
-                        uint2 o;
-                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(outp + e0) = o;
-                    }
-                }
-            }
-        }
-    }
-    if (p.stats) {                                         // uniform
-        // fold the 16 pixel lanes of a row (DPP), one atomic pair per channel and wave
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s1[e] = dw_row16_sum(s1[e]); s2a[e] = dw_row16_sum(s2a[e]); }
-        if (j == 0 && cq_ok) {
-            float* dst = p.stats + (long)(bxi % p.stat_reps) * 2 * p.C;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(dst + cq + e, s1[e]);
-                atomicAdd(dst + p.C + cq + e, s2a[e]);
-            }
-        }
-    }
-}
-
-template <int MODE>
-inline int launch_dw6(const void* in, const void* w9, void* out, int N, int C, int H, int W, int dil, int flip,
-                      hipStream_t st, float* stats = nullptr, int stat_reps = 1, Dw4Bn bn = Dw4Bn{}) {
-    const long in_bytes = (long)N * H * W * C * 2;
-    if (in_bytes >= (1L << 31) - (1L << 24) || W < 8) return -2;
-    const int rowpx = (W + 2 * dil + 7) / 8 * 8;
-    const long row_bytes = (long)rowpx * 128;
-    // the last 16-pixel segment of a row may read past the row's end — into the next ring slot, or, from the last
-    // slot, into this guard band; what it reads there only reaches output pixels >= W, which are not stored
-    const long guard = (long)(16 + 2 * dil) * 128;
-    int TS = 4 < H ? 4 : H;                             // two resident blocks per CU when a ring fits in 80 KiB
-    while (TS >= 1 && (2 * TS + 2 * dil) * row_bytes + guard > 80 * 1024) --TS;
-    if (TS < 1) return -2;                              // generation 4 takes the wide maps (one block per CU)
-    const int NR = 2 * TS + 2 * dil;
-    const long lds = NR * row_bytes + guard;
-    const long slabs = (C + 63) / 64, slots = 256L * 2;
-    int best_hs = 1;
-    long best_cost = -1;
-    for (int hs = 1; hs <= 4; ++hs) {
-        const int rows = (H + hs - 1) / hs;
-        if (hs > 1 && rows < 2 * TS) break;
-        const long bands = (H + rows - 1) / rows;
-        const long rounds = (N * slabs * bands + slots - 1) / slots;
-        const long cost = rounds * (rows + 2 * dil);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_hs = hs; }
-    }
-    const int rows_split = (H + best_hs - 1) / best_hs;
-    const int hsplit = (H + rows_split - 1) / rows_split;
-    const long nb = (long)N * hsplit;
-    if (nb > 0x7fffffffL) return -4;
-    Dw4 p{(const bf16_raw*)in, nullptr, (const bf16_raw*)w9, out, N, C, H, W, dil, TS, NR, hsplit, rows_split,
-          flip, rowpx, (unsigned)in_bytes, stats, stat_reps < 1 ? 1 : stat_reps,
-          (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd, bn.w, bn.b};
-    auto kfn = dwconv6_kernel<MODE>;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); once = true; }
-    if (nb * slabs > 0x7fffffffL) return -4;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(nb * slabs)), dim3(256), (size_t)lds, st, p);
-    return DP_LAUNCH_STATUS();
-}
-
-// 4 = rolling row window (default); 5 = as 4, with the weight gradient on the matrix cores (opt-in: measured
-// slower, see dwconv5_wgrad_kernel); 3 = LDS row tiles, 2 / 1 = the strip / flat mappings
-static int kDwGen = getenv("DPAMD_DWCONV_GEN") ? atoi(getenv("DPAMD_DWCONV_GEN")) : 4;
 
 }  // namespace
 
-// tests / tools: select the kernel generation at run time (returns the previous one)
-DP_EXPORT int dp_dwconv_set_gen(int gen) {
-    const int old = kDwGen;
-    if (gen >= 1 && gen <= 7) kDwGen = gen;
+// tests / tools: rolling-window kernels on or off at run time (returns the previous setting)
+DP_EXPORT int dp_dwconv_set_window(int on) {
+    const int old = kDwWindow;
+    kDwWindow = on ? 1 : 0;
     return old;
 }
 
 DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
                             int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
-    if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
-        if (kDwGen >= 6) {
-            const int rc = launch_dw6<0>(x, w9, y, N, C, Hi, Wi, dil, 0, st);
-            if (rc != -2) return rc;
-        }
-        if (kDwGen >= 4) {
-            const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st);
-            if (rc != -2) return rc;
-        }
-        const int th = dw3_rows(Hi, Wi, dil, false);
-        if (th > 0) {
-            const int rc = launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st);
-            if (rc != -2) return rc;
-        }
+    if (dw_same(stride, pad_h, pad_w, dil, Hi, Wi, Ho, Wo)) {
+        const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st);
+        if (rc != -2) return rc;
     }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
-    // strip mapping measured SLOWER here than the flat mapping (176 vs 111 us on the 728-channel 65x65
-    // layers: a wave's loads split into two 512-B runs and a thread walks 8 pixels serially); it pays
-    // only in bwd_weight, where it removes the per-pixel register spill of partial sums.  Opt-in: =2.
-    static const bool gen2 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 2;
-    const long P = (long)N * Ho * Wo;
-    const long nb = (P + kStrips * 8 - 1) / (kStrips * 8);
-    if (gen2 && nb <= 0x7fffffffL) {
-        hipLaunchKernelGGL(dwconv2_fwd_kernel<8>, dim3((unsigned)nb, (unsigned)((C / 8 + kSlab - 1) / kSlab)), dim3(256),
-                           0, st, (const bf16_raw*)x, (const bf16_raw*)w9, (bf16_raw*)y, p);
-        return DP_LAUNCH_STATUS();
-    }
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_1d((long)N * Ho * Wo * (C / 8), 256)), dim3(256), 0, st,
                        (const bf16_raw*)x, (const bf16_raw*)w9, (bf16_raw*)y, p);
     return DP_LAUNCH_STATUS();
@@ -1500,94 +743,55 @@ DP_EXPORT int dp_dwconv_fwd(const void* x, const void* w9, void* y, int N, int C
 DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N, int C, int Hi, int Wi, int Ho,
                                  int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
-    if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
-        if (kDwGen >= 6) {                                           // = forward over dy with the taps flipped
-            const int rc = launch_dw6<0>(dy, w9, dx, N, C, Hi, Wi, dil, 1, st);
-            if (rc != -2) return rc;
-        }
-        if (kDwGen >= 4) {
-            const int rc = launch_dw4<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, st);
-            if (rc != -2) return rc;
-        }
-        const int th = dw3_rows(Hi, Wi, dil, false);
-        if (th > 0) {
-            const int rc = launch_dw3<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, th, st);
-            if (rc != -2) return rc;
-        }
+    if (dw_same(stride, pad_h, pad_w, dil, Hi, Wi, Ho, Wo)) {       // = forward over dy with the taps flipped
+        const int rc = launch_dw4<0>(dy, nullptr, w9, dx, N, C, Hi, Wi, dil, 1, st);
+        if (rc != -2) return rc;
     }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
-    static const bool gen2 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 2;   // see dp_dwconv_fwd
-    const long Pin = (long)N * Hi * Wi;
-    const long nbs = (Pin + kStrips * 8 - 1) / (kStrips * 8);
-    if (gen2 && stride == 1 && nbs <= 0x7fffffffL) {
-        hipLaunchKernelGGL(dwconv2_bwd_data_kernel<8>, dim3((unsigned)nbs, (unsigned)((C / 8 + kSlab - 1) / kSlab)),
-                           dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)w9, (bf16_raw*)dx, p);
-        return DP_LAUNCH_STATUS();
-    }
     hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_1d((long)N * Hi * Wi * (C / 8), 256)), dim3(256), 0, st,
                        (const bf16_raw*)dy, (const bf16_raw*)w9, (bf16_raw*)dx, p);
     return DP_LAUNCH_STATUS();
 }
 
-DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int N, int C, int Hi, int Wi, int Ho,
-                                   int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
-    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1) return -1;
-    if (kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi) {
-        if (kDwGen == 5) {
-            const int rc = launch_dw5w(x, dy, dw9, N, C, Hi, Wi, dil, st);
-            if (rc != -2) return rc;
-        }
-        if (kDwGen >= 4) {
-            const int rc = launch_dw4<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, st);
-            if (rc != -2) return rc;
-        }
-        const int th = dw3_rows(Hi, Wi, dil, true);
-        if (th > 0) {
-            const int rc = launch_dw3<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, th, st);
-            if (rc != -2) return rc;
-        }
+// dw9: fp32 [reps][9][C], zero-initialised (or holding a gradient to accumulate into); block b adds into replica
+// b % reps.  reps = 1 is the normal call; dp_dwconv_wgrad_blocks() returns the replica count that gives every
+// block a buffer of its own (deterministic mode: no two blocks add into one address).
+DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int reps, int N, int C, int Hi, int Wi,
+                                   int Ho, int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || reps < 1) return -1;
+    if (dw_same(stride, pad_h, pad_w, dil, Hi, Wi, Ho, Wo)) {
+        const int rc = launch_dw4<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, st, nullptr, reps);
+        if (rc != -2) return rc;
     }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
     const int C8 = C / 8;
-    static const bool gen1 = getenv("DPAMD_DWCONV_GEN") && atoi(getenv("DPAMD_DWCONV_GEN")) == 1;
-    {
-        const long P = (long)N * Ho * Wo;
-        const long nbw = (P + kStrips * 32 - 1) / (kStrips * 32);
-        if (!gen1 && nbw <= 0x7fffffffL) {
-            hipLaunchKernelGGL(dwconv2_bwd_weight_kernel<32>, dim3((unsigned)nbw, (unsigned)((C8 + kSlab - 1) / kSlab)),
-                               dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p);
-            return DP_LAUNCH_STATUS();
-        }
-    }
-    const int cgs = C8 < 256 ? C8 : 256;
-    const int rpp = 256 / cgs;
-    long nb = ((long)N * Ho * Wo + (long)rpp * 8 - 1) / ((long)rpp * 8);
-    if (nb < 1) nb = 1;
-    if (nb > 512) nb = 512;
-    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3((unsigned)nb, (unsigned)((C8 + 255) / 256)), dim3(256), 0, st,
-                       (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p);
+    const long P = (long)N * Ho * Wo;
+    const long nbw = (P + kStrips * 32 - 1) / (kStrips * 32);
+    if (nbw > 0x7fffffffL) return -4;
+    hipLaunchKernelGGL(dwconv2_bwd_weight_kernel<32>, dim3((unsigned)nbw, (unsigned)((C8 + kSlab - 1) / kSlab)),
+                       dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p, reps);
     return DP_LAUNCH_STATUS();
 }
 
+// Upper bound of the number of row blocks (grid.x, or image bands of the rolling-window kernels) any depthwise
+// launch of this shape uses: the replica count under which no two blocks share a statistics / weight-gradient
+// replica.
+DP_EXPORT long dp_dwconv_row_blocks(int N, int H, int W, int Ho, int Wo) {
+    const long wsplit = (W + 32 * kDw4K - 1) / (32 * kDw4K);
+    const long window = (long)N * 4 * wsplit;                                  // hsplit <= 4
+    const long strip = ((long)N * Ho * Wo + kStrips * 32 - 1) / (kStrips * 32);
+    return window > strip ? window : strip;
+}
+
 // Forward with fused BatchNorm statistics: stats fp32 [stat_reps][2][C], zero-initialised, receives the
-// per-channel sums of y and y^2.  Returns -2 when the LDS row-tiled kernel does not take the shape (the
+// per-channel sums of y and y^2.  Returns -2 when the rolling-window kernel does not take the shape (the
 // caller then runs dp_dwconv_fwd and a separate statistics pass).
 DP_EXPORT int dp_dwconv_fwd_stats(const void* x, const void* w9, void* y, float* stats, int stat_reps, int N, int C,
                                   int Hi, int Wi, int Ho, int Wo, int stride, int pad_h, int pad_w, int dil,
                                   hipStream_t st) {
     if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || !stats || stat_reps < 1) return -1;
-    if (!(kDwGen >= 3 && stride == 1 && pad_h == dil && pad_w == dil && Ho == Hi && Wo == Wi)) return -2;
-    if (kDwGen >= 6) {
-        const int rc = launch_dw6<0>(x, w9, y, N, C, Hi, Wi, dil, 0, st, stats, stat_reps);
-        if (rc != -2) return rc;
-    }
-    if (kDwGen >= 4) {
-        const int rc = launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st, stats, stat_reps);
-        if (rc != -2) return rc;
-    }
-    const int th = dw3_rows(Hi, Wi, dil, false);
-    if (th <= 0) return -2;
-    return launch_dw3<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, th, st, stats, stat_reps);
+    if (!dw_same(stride, pad_h, pad_w, dil, Hi, Wi, Ho, Wo)) return -2;
+    return launch_dw4<0>(x, nullptr, w9, y, N, C, Hi, Wi, dil, 0, st, stats, stat_reps);
 }
 
 // Data gradient (stride 1, "same" padding) with the skip-path gradient `res` (or null) added and, when bnx is given,
@@ -1604,12 +808,7 @@ DP_EXPORT int dp_dwconv_bwd_data_fused(const void* dy, const void* w9, void* dx,
     if (bnx && (!bn_mean || !bn_rstd || !sums || reps < 1)) return -1;
     if (!bnx && !res) return -1;
     if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)res | (uintptr_t)bna | (uintptr_t)bnx | (uintptr_t)w9) & 15) return -3;
-    if (kDwGen < 4) return -2;
-    if (kDwGen >= 7) {
-        const int rc = launch_dw6<1>(dy, w9, dx, N, C, H, W, dil, 1, st, bnx ? sums : nullptr, reps,
-                                     Dw4Bn{res, bna, bnx, bn_mean, bn_rstd, bn_w, bn_b});
-        if (rc != -2) return rc;
-    }
+    if (!kDwWindow) return -2;
     return launch_dw4<1>(dy, nullptr, w9, dx, N, C, H, W, dil, 1, st, bnx ? sums : nullptr, reps,
                          Dw4Bn{res, bna, bnx, bn_mean, bn_rstd, bn_w, bn_b});
 }

@@ -48,11 +48,12 @@ __device__ __forceinline__ void stage_rows_out(bf16_raw* __restrict__ g, const b
     for (long i = (vec << 3) + threadIdx.x; i < elems; i += kCeThreads) dst[i] = lds[i];
 }
 
-// out[0] += Σ loss, out[1] += #valid
+// out[0] += Σ loss, out[1] += #valid; out is [reps][2] and block b adds into pair b % reps
 template <typename LabelT>
 __global__ __launch_bounds__(kCeThreads) void softmax_ce_fwd_kernel(const bf16_raw* __restrict__ logits,
                                                                     const void* __restrict__ target, long M, int C,
-                                                                    int ignore_index, float* __restrict__ out) {
+                                                                    int ignore_index, float* __restrict__ out, int reps) {
+    out += 2 * (blockIdx.x % (unsigned)reps);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_raw* tile = reinterpret_cast<bf16_raw*>(smem_raw);
     float loss = 0.f, cnt = 0.f;
@@ -261,13 +262,13 @@ inline int grid_1d(long total, int threads, int cap = 256 * 16) {
 
 // label_kind: 0 = uint8, 1 = int32, 2 = int64
 DP_EXPORT int dp_softmax_ce_fwd(const void* logits, const void* target, int label_kind, long M, int C,
-                                int ignore_index, float* out2, hipStream_t st) {
-    if (M <= 0 || C <= 0 || C > 1024) return -1;
+                                int ignore_index, float* out2, int reps, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C > 1024 || reps < 1) return -1;
     const size_t lds = ((size_t)kCeThreads * C * sizeof(bf16_raw) + 63) / 64 * 64;
     if (lds > 64 * 1024) return -2;
     const int grid = grid_1d(M, kCeThreads, 2048);
 #define LAUNCH_FWD(T) hipLaunchKernelGGL(softmax_ce_fwd_kernel<T>, dim3(grid), dim3(kCeThreads), lds, st, \
-                                         (const bf16_raw*)logits, target, M, C, ignore_index, out2)
+                                         (const bf16_raw*)logits, target, M, C, ignore_index, out2, reps)
     if (label_kind == 0) LAUNCH_FWD(unsigned char);
     else if (label_kind == 1) LAUNCH_FWD(int);
     else LAUNCH_FWD(long long);

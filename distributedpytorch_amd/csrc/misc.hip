@@ -322,6 +322,13 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const bf16_raw* __restri
 
 }  // namespace
 
+int g_dp_deterministic = 0;
+DP_EXPORT int dp_set_deterministic(int on) {
+    const int old = g_dp_deterministic;
+    g_dp_deterministic = on ? 1 : 0;
+    return old;
+}
+
 DP_EXPORT int dp_sgd_flat(float* p, float* g, float* m, void* p16, long n, float lr, float mu, float wd,
                           float gscale, int zero_grad, int first, hipStream_t st) {
     if (n <= 0) return 0;

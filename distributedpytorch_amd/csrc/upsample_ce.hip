@@ -30,7 +30,8 @@ constexpr int BT_H = 4, BT_W = 8;             // backward: low-res tile
 struct UpCeArgs {
     const bf16_raw* x;       // low-res logits [N, Hi, Wi, ld]
     const void* target;      // [N, Ho, Wo]
-    float* sums;             // [2]: Σloss, #valid
+    float* sums;             // [sum_reps][2]: Σloss, #valid (forward: block b adds into pair b % sum_reps)
+    int sum_reps;
     const float* gloss;      // backward: upstream gradient (device scalar)
     bf16_raw* dx;            // backward: [N, Hi, Wi, ldo]
     int N, C, ld, ldo, Hi, Wi, Ho, Wo, ignore_index;
@@ -134,8 +135,9 @@ __global__ __launch_bounds__(kT) void upsample_ce_fwd_kernel(UpCeArgs p) {
         float l = 0.f, c2 = 0.f;
         for (int w = 0; w < kT / kWave; ++w) { l += red[w]; c2 += red[kT / kWave + w]; }
         if (c2 > 0.f) {
-            atomicAdd(p.sums + 0, l);
-            atomicAdd(p.sums + 1, c2);
+            float* dst = p.sums + 2 * (blockIdx.x % (unsigned)p.sum_reps);
+            atomicAdd(dst + 0, l);
+            atomicAdd(dst + 1, c2);
         }
     }
 }
@@ -302,8 +304,10 @@ inline bool fill_args(UpCeArgs& p, int N, int C, int ld, int Hi, int Wi, int Ho,
 
 // Returns -2 when the shape is outside what the fused kernels take (caller runs the unfused pair).
 DP_EXPORT int dp_upsample_ce_fwd(const void* x, const void* target, int label_kind, int N, int C, int ld, int Hi,
-                                 int Wi, int Ho, int Wo, int ignore_index, float* sums, hipStream_t st) {
+                                 int Wi, int Ho, int Wo, int ignore_index, float* sums, int sum_reps, hipStream_t st) {
     UpCeArgs p{};
+    if (sum_reps < 1) return -1;
+    p.sum_reps = sum_reps;
     if (!fill_args(p, N, C, ld, Hi, Wi, Ho, Wo, ignore_index)) return -2;
     const size_t lds = (size_t)FF_H * FF_W * C * sizeof(float);
     if (lds > 60 * 1024) return -2;

@@ -34,6 +34,57 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+# ---- deterministic mode -----------------------------------------------------------------------------------
+# Every cross-block reduction of the kernels (BN statistics in the conv epilogues, fused BN-backward sums,
+# split-K weight gradients, depthwise weight gradients, attention dQ / gram, loss sums) is a float atomic: the
+# sum depends on the arrival order and two launches of one binary differ in the last bits — bits that a
+# BatchNorm+ReLU stack amplifies (profiles/r3_nondeterminism_*.md).  With DPAMD_DETERMINISTIC=1 /
+# ``set_deterministic(True)`` no address has two concurrent writers: statistics and depthwise weight gradients get
+# one replica per block (summed afterwards by a fixed-order reduction), weight gradients run with split-K = 1,
+# the standalone reduction kernels with one row split, attention dQ through per-key-block partials, tile
+# configurations come from the packaged table or the default (no timing-dependent autotuning), and the
+# auxiliary weight-gradient stream is off.  Two launches are then BIT-identical.  Slower (x1.2-3): a mode for
+# bisecting regressions and for tests, not for training runs.
+_deterministic = os.environ.get("DPAMD_DETERMINISTIC", "0") not in ("0", "")
+_det_synced = False
+
+
+def deterministic() -> bool:
+    return _deterministic
+
+
+def set_deterministic(flag: bool) -> bool:
+    """Turn the deterministic mode on / off; returns the previous setting."""
+    global _deterministic, _det_synced
+    old, _deterministic = _deterministic, bool(flag)
+    _det_synced = False
+    if _lib is not None:
+        _sync_det()
+    return old
+
+
+def _sync_det() -> None:
+    global _det_synced
+    if not _det_synced and _lib is not None:
+        _lib.dp_set_deterministic(int(_deterministic))
+        _det_synced = True
+
+
+class deterministic_mode:
+    """Context manager: ``with deterministic_mode(): ...``"""
+
+    def __init__(self, flag: bool = True):
+        self.flag = flag
+
+    def __enter__(self):
+        self.prev = set_deterministic(self.flag)
+        return self
+
+    def __exit__(self, *exc):
+        set_deterministic(self.prev)
+        return False
+
+
 def set_backend(mode: str) -> None:
     global _mode
     if mode not in ("auto", "torch"):
@@ -113,6 +164,7 @@ def lib() -> ctypes.CDLL:
                 else:
                     _ensure_current()
                     _lib = ctypes.CDLL(LIB_PATH)
+                _sync_det()
     return _lib
 
 

@@ -11,7 +11,7 @@ a kernel.
 from __future__ import annotations
 
 import os
-from ctypes import c_int, c_void_p
+from ctypes import c_int, c_long, c_void_p
 from typing import Optional, Tuple
 
 import torch
@@ -31,9 +31,8 @@ def _lib():
         lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
-        lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 8 + [I, V]
+        lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 9 + [I, V]
         lib.dp_conv_igemm2ra.argtypes = [V, V, V] + [I] * 16 + [V] * 4
-        lib.dp_conv_set_bnmask.argtypes = [V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -43,7 +42,9 @@ def _lib():
         lib.dp_dwconv_bwd_data_fused.argtypes = [V] * 11 + [I] * 6 + [V]
         lib.dp_dwconv_fwd_stats.argtypes = [V, V, V, V] + [I] * 11 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
-        lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 10 + [V]
+        lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 11 + [V]
+        lib.dp_dwconv_row_blocks.argtypes = [I] * 5
+        lib.dp_dwconv_row_blocks.restype = c_long
         _sigs_done = True
     return lib
 
@@ -121,7 +122,9 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
     if cfg is None:
         key = (n, hi, wi, cin, ho, wo, cout, r, s, smul, sdiv, pad, dil, bias is not None, stats is not None)
         cfg = _TUNED.get(key)
-        if cfg is None:
+        if cfg is None and B.deterministic():
+            cfg = 1                    # no timing-dependent choice: the table's tile or the default
+        elif cfg is None:
             cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device) if _AUTOTUNE else 1
             _save_tuned()
     if residual is not None:
@@ -294,16 +297,18 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
         for n0 in range(0, n, nper):         # (one launch unless the gradient passes the kernels' 32-bit offsets)
             n1 = min(n, n0 + nper)
             sl = (lambda t: t[n0:n1] if t is not None else None)
-            if bits is not None:
-                _lib().dp_conv_set_bnmask(B.ptr(bits.view(-1)[n0 * bits_img:]))       # consumed by the launch below
+            mask = bits.view(-1)[n0 * bits_img:] if bits is not None else None
             st = _lib().dp_conv_igemm2b(B.ptr(dy[n0:n1]), B.ptr(wt), B.ptr(y[n0:n1]), n1 - n0, hi, wi, cin, ho, wo, cout,
                                         r, s, 1, sdiv, pad[0], pad[1], dil[0], dil[1], c, B.ptr(sl(residual)),
-                                        B.ptr(bx[n0:n1]), B.ptr(sl(ba)), B.ptr(holder["mean"]), B.ptr(holder["invstd"]),
-                                        B.ptr(holder.get("w")), B.ptr(holder.get("b")), sums_ptr, reps, stream)
+                                        B.ptr(bx[n0:n1]), B.ptr(sl(ba)), B.ptr(mask), B.ptr(holder["mean"]),
+                                        B.ptr(holder["invstd"]), B.ptr(holder.get("w")), B.ptr(holder.get("b")),
+                                        sums_ptr, reps, stream)
             if st != 0:
                 break
         return st
-    if cfg is None:
+    if cfg is None and B.deterministic():
+        cfg = 1
+    elif cfg is None:
         if _AUTOTUNE:
             scratch = torch.zeros(reps * 2 * cout, dtype=torch.float32, device=dy.device)
             cfg = _autotune((), None, 1, cout, dy.device,
@@ -314,12 +319,12 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
         _save_tuned()
     if cfg <= 0:
         return None
-    sums = workspace.zeros(reps * 2 * cout, dy.device).view(reps, 2, cout)
+    sums = stats_buffer(reps, cout, dy.device)
     st = launch(cfg, B.ptr(sums), B.stream_ptr())
     if st == -2:
         return None
     B.check(st, "conv_igemm2b")
-    return y, sums           # [reps, 2, Cout] partial sums: BN backward's apply kernel folds the replicas
+    return y, fold_stats(sums)           # [reps, 2, Cout] partial sums: BN backward's apply kernel folds the replicas
 
 
 def weight_transpose(w_krsc: torch.Tensor) -> torch.Tensor:
@@ -349,9 +354,34 @@ def weight_transpose_batched(src: torch.Tensor, dst: torch.Tensor, table: torch.
 
 
 def stat_replicas(m_rows: int) -> int:
-    """Replica count for the fused-statistics accumulators: ~one replica per 64 M-tiles, ≤ 8."""
+    """Replica count for the fused-statistics accumulators: ~one replica per 64 M-tiles, ≤ 8.  Deterministic mode:
+    one replica per M-tile of the smallest tile height (128 rows; the kernels index ``tile_m % replicas``), so no
+    two blocks add into one address; ``fold_stats`` then sums the replicas in a fixed order."""
     tiles = (m_rows + 127) // 128
+    if B.deterministic():
+        return max(1, tiles)
     return max(1, min(8, tiles // 64))
+
+
+def stats_buffer(reps: int, c: int, device) -> torch.Tensor:
+    """Zeroed fp32 [reps, 2, c] accumulator (the per-step scratch pool; a fresh tensor in deterministic mode,
+    whose replica counts would drain the pool)."""
+    if B.deterministic():
+        return torch.zeros(reps, 2, c, dtype=torch.float32, device=device)
+    return workspace.zeros(reps * 2 * c, device).view(reps, 2, c)
+
+
+def fold_stats(stats: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Deterministic mode: the per-block replicas -> ONE [1, 2, C] block by a fixed-order sum (the consumers'
+    own replica loops are meant for <= 8).  Otherwise the tensor as it is."""
+    if stats is not None and B.deterministic() and stats.shape[0] > 1:
+        return stats.sum(0, keepdim=True)
+    return stats
+
+
+def dw_row_blocks(n: int, hi: int, wi: int, ho: int, wo: int) -> int:
+    """Replica count under which no two blocks of a depthwise launch share a replica (deterministic mode)."""
+    return max(1, int(_lib().dp_dwconv_row_blocks(n, hi, wi, ho, wo)))
 
 
 # BN+ReLU backward's mask and reductions run inside the consumer's data-gradient store loop
@@ -383,7 +413,9 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
         for n0 in range(0, n, nper):         # split-K over image chunks: every launch adds into the same dw
             wgrad(dy[n0:n0 + nper], x[n0:n0 + nper], wshape, stride, pad, dil, out=dw, splits=splits)
         return dw
-    if splits == 0 and _AUTOTUNE and not _WGRAD_GEN1:
+    if B.deterministic():
+        splits = 1                       # one block per output tile: its atomics meet a zero or stream-ordered sum
+    elif splits == 0 and _AUTOTUNE and not _WGRAD_GEN1:
         key = ("wgrad", n, hi, wi, cin, ho, wo, cout, r, s, tuple(stride), tuple(pad), tuple(dil))
         splits = _TUNED.get(key)
         if splits is None:
@@ -470,8 +502,9 @@ class _ConvIGemm(torch.autograd.Function):
             if cout_p != cout:
                 raise ValueError("fused statistics need Cout % 8 == 0")
             reps = stat_replicas(n * ho * wo)
-            stats = workspace.zeros(reps * 2 * cout, x.device).view(reps, 2, cout)
+            stats = stats_buffer(reps, cout, x.device)
         y = igemm(x, w_used, (ho, wo), stride[0], 1, padding, dilation, b32, stats)
+        stats = fold_stats(stats)
         ctx.save_for_backward(x, w_used)
         ctx.geom = (stride, padding, dilation, (cout, cin, r, s), (hi, wi), cout_p, cin_p)
         ctx.has_bias = bias is not None
@@ -608,12 +641,14 @@ class _StemConv(torch.autograd.Function):
         reps = 1
         if with_stats:
             reps = stat_replicas(n * ho * wo)
-            stats = workspace.zeros(reps * 2 * cout, x.device).view(reps, 2, cout)
+            stats = stats_buffer(reps, cout, x.device)
         args = (B.ptr(xp), B.ptr(w32), B.ptr(y), None, B.ptr(stats), reps, n, hi, wp_px, _STEM_WINDOW, ho, wo, cout,
                 r, 1, stride[0], 1, padding[0], 0, 1, 1, cout)
         key = ("stem", n, hi, wp_px, ho, wo, cout, r, stride[0], padding[0], with_stats)
         cfg = _FORCED_CFG if _FORCED_CFG else _TUNED.get(key)
-        if cfg is None:
+        if cfg is None and B.deterministic():
+            cfg = 7
+        elif cfg is None:
             def runner(a, c, stream):
                 return -2 if c == 0 else _lib().dp_conv_igemm2w(*a, c, 4, stream)
             cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device, runner,
@@ -625,6 +660,7 @@ class _StemConv(torch.autograd.Function):
         ctx.weight_param = weight
         ctx.set_materialize_grads(False)
         if with_stats:
+            stats = fold_stats(stats)
             ctx.mark_non_differentiable(stats)
             return y, stats
         return y
@@ -650,7 +686,9 @@ class _StemConv(torch.autograd.Function):
                     break
             return st
         splits = 0
-        if _AUTOTUNE:
+        if B.deterministic():
+            splits = 1
+        elif _AUTOTUNE:
             key = ("stem_wgrad", n, hi, wp_px, ho, wo, cout, r, stride[0], padding[0])
             splits = _TUNED.get(key)
             if splits is None:
@@ -694,8 +732,8 @@ class _DepthwiseConv(torch.autograd.Function):
         spans = [(n0, min(n, n0 + nper)) for n0 in range(0, n, nper)]
         if with_stats:
             # BatchNorm statistics from the kernel's own accumulators (csrc/depthwise.hip, Dw3::stats)
-            reps = stat_replicas(n * ho * wo)
-            stats = workspace.zeros(reps * 2 * c, x.device).view(reps, 2, c)
+            reps = dw_row_blocks(nper, hi, wi, ho, wo) if B.deterministic() else stat_replicas(n * ho * wo)
+            stats = stats_buffer(reps, c, x.device)
             for i, (n0, n1) in enumerate(spans):
                 st = _lib().dp_dwconv_fwd_stats(B.ptr(x[n0:n1]), B.ptr(w9), B.ptr(y[n0:n1]), B.ptr(stats), reps, n1 - n0, c,
                                                 hi, wi, ho, wo, stride[0], padding[0], padding[1], dilation[0],
@@ -719,6 +757,7 @@ class _DepthwiseConv(torch.autograd.Function):
                 from . import _hip_bn
                 s1, s2 = _hip_bn.stats(y)
                 stats = torch.stack([s1, s2]).unsqueeze(0)
+            stats = fold_stats(stats)
             ctx.mark_non_differentiable(stats)
             outs.append(stats)
         if passthrough:
@@ -754,8 +793,8 @@ class _DepthwiseConv(torch.autograd.Function):
                 if bx is not None or dskip is not None:
                     sums, reps = None, 1
                     if bx is not None:
-                        reps = stat_replicas(n * hi * wi)
-                        sums = workspace.zeros(reps * 2 * c, x.device).view(reps, 2, c)
+                        reps = dw_row_blocks(nper, hi, wi, ho, wo) if B.deterministic() else stat_replicas(n * hi * wi)
+                        sums = stats_buffer(reps, c, x.device)
                     # mask source: the activation itself (= this node's input) where a residual entered it, else
                     # recomputed from the BatchNorm input the kernel reads anyway (one tensor less to fetch)
                     ba = x if (bx is not None and h.get("mask_from_a")) else None
@@ -773,7 +812,7 @@ class _DepthwiseConv(torch.autograd.Function):
                     if st != -2:
                         fused = True
                         if bx is not None:
-                            h["sums"] = sums
+                            h["sums"] = fold_stats(sums)
                             h["dm_ptr"] = dx.data_ptr()
             if not fused:
                 for n0, n1 in spans:
@@ -789,7 +828,12 @@ class _DepthwiseConv(torch.autograd.Function):
             if notify is not None:
                 notify(ctx.weight_param)
         elif ctx.needs_input_grad[1]:
-            dw9 = workspace.zeros(9 * c, x.device).view(9, c)
+            wreps = dw_row_blocks(nper, hi, wi, ho, wo) if B.deterministic() else 1
+            if wreps > 1:
+                dw9r = torch.zeros(wreps, 9, c, dtype=torch.float32, device=x.device)
+            else:
+                dw9r = workspace.zeros(9 * c, x.device).view(1, 9, c)
+            dw9 = dw9r[0]
             wp = ctx.weight_param
             sink = getattr(wp, "_dpamd_grad_sink", None)
             if (sink is not None and wp.grad is not None and wp.grad.data_ptr() == sink.data_ptr()
@@ -799,20 +843,23 @@ class _DepthwiseConv(torch.autograd.Function):
                 aux = streams.fork(dy.device)
                 with torch.cuda.stream(aux):
                     for n0, n1 in spans:
-                        B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(dw9), n1 - n0, c, hi, wi,
-                                                            ho, wo, stride[0], padding[0], padding[1], dilation[0],
+                        B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(dw9r), wreps, n1 - n0, c,
+                                                            hi, wi, ho, wo, stride[0], padding[0], padding[1], dilation[0],
                                                             B.stream_ptr()), "dwconv_bwd_weight")
-                    sink.view(c, 9).add_(dw9.t())
+                    sink.view(c, 9).add_((dw9r.sum(0) if wreps > 1 else dw9).t())
                 dy.record_stream(aux)
                 x.record_stream(aux)
+                dw9r.record_stream(aux)      # (a pool slice or a fresh tensor: either way written and read on aux)
                 notify = getattr(wp, "_dpamd_on_grad", None)
                 if notify is not None:
                     notify(wp)
             else:
                 for n0, n1 in spans:
-                    B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(dw9), n1 - n0, c, hi, wi, ho,
-                                                        wo, stride[0], padding[0], padding[1], dilation[0],
+                    B.check(_lib().dp_dwconv_bwd_weight(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(dw9r), wreps, n1 - n0, c, hi,
+                                                        wi, ho, wo, stride[0], padding[0], padding[1], dilation[0],
                                                         B.stream_ptr()), "dwconv_bwd_weight")
+                if wreps > 1:
+                    dw9 = dw9r.sum(0)
                 dw = dw9.t().reshape(c, 1, 3, 3).contiguous()
         return dx, dw, None, None, None, None, None, None, None
 

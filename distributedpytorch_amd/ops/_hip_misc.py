@@ -17,9 +17,9 @@ def _lib():
     lib = B.lib()
     if not _sigs_done:
         V, I, L, F = c_void_p, c_int, c_long, c_float
-        lib.dp_softmax_ce_fwd.argtypes = [V, V, I, L, I, I, V, V]
+        lib.dp_softmax_ce_fwd.argtypes = [V, V, I, L, I, I, V, I, V]
         lib.dp_softmax_ce_bwd.argtypes = [V, V, I, L, I, I, V, V, V, V]
-        lib.dp_upsample_ce_fwd.argtypes = [V, V, I, I, I, I, I, I, I, I, I, V, V]
+        lib.dp_upsample_ce_fwd.argtypes = [V, V, I, I, I, I, I, I, I, I, I, V, I, V]
         lib.dp_upsample_ce_bwd.argtypes = [V, V, I, I, I, I, I, I, I, I, I, I, V, V, V, V]
         lib.dp_bilinear_fwd.argtypes = [V, V, I, I, I, I, I, I, V]
         lib.dp_bilinear_bwd.argtypes = [V, V, I, I, I, I, I, I, V]
@@ -67,13 +67,18 @@ def _label(target: torch.Tensor, shape) -> Tuple[torch.Tensor, int]:
 
 
 # ------------------------------------------------------------------ softmax CE
+_LOSS_REPS = 2048      # >= the largest grid of the loss kernels (csrc/loss_upsample.hip, csrc/upsample_ce.hip)
+
+
 def softmax_ce_fwd(logits: torch.Tensor, target: torch.Tensor, ignore_index: int):
     logits = _req_bf16_nhwc(logits, "logits")
     n, c, h, w = logits.shape
     target, kind = _label(target, (n, h, w))
-    sums = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    reps = _LOSS_REPS if B.deterministic() else 1         # one (loss, count) pair per block, summed in order
+    sums = torch.zeros(reps, 2, dtype=torch.float32, device=logits.device)
     B.check(_lib().dp_softmax_ce_fwd(B.ptr(logits), B.ptr(target), kind, n * h * w, c, int(ignore_index),
-                                     B.ptr(sums), B.stream_ptr()), "softmax_ce_fwd")
+                                     B.ptr(sums), reps, B.stream_ptr()), "softmax_ce_fwd")
+    sums = sums.sum(0) if reps > 1 else sums[0]
     loss = sums[0] / sums[1].clamp_min(1.0)
     return loss, sums, logits, target
 
@@ -109,12 +114,14 @@ def upsample_ce_fwd(logits: torch.Tensor, target: torch.Tensor, ignore_index: in
     n, c, hi, wi = x.shape
     ho, wo = target.shape[1:]
     target, kind = _label(target, (n, ho, wo))
-    sums = torch.zeros(2, dtype=torch.float32, device=x.device)
+    reps = _LOSS_REPS if B.deterministic() else 1
+    sums = torch.zeros(reps, 2, dtype=torch.float32, device=x.device)
     st = _lib().dp_upsample_ce_fwd(B.ptr(x), B.ptr(target), kind, n, c, ld, hi, wi, ho, wo, int(ignore_index),
-                                   B.ptr(sums), B.stream_ptr())
+                                   B.ptr(sums), reps, B.stream_ptr())
     if st == -2:
         return None
     B.check(st, "upsample_ce_fwd")
+    sums = sums.sum(0) if reps > 1 else sums[0]
     return sums[0] / sums[1].clamp_min(1.0), sums, x, target, ld
 
 

@@ -35,34 +35,40 @@ _MASK_BITS = os.environ.get("DPAMD_BN_MASK_BITS", "1") != "0"
 # --------------------------------------------------------------------------------------
 # primitives (torch math = CPU path and numerical reference)
 # --------------------------------------------------------------------------------------
+def _f(t: torch.Tensor) -> torch.Tensor:
+    """fp32 working precision — or fp64 when the caller runs the torch path in double (tools/diag_nondeterminism.py:
+    the fp64 reference the kernels' gradients are judged against)."""
+    return t if t.dtype == torch.float64 else t.float()
+
+
 def _t_stats(x: torch.Tensor):
-    xf = x.float()
+    xf = _f(x)
     return xf.sum(dim=(0, 2, 3)), (xf * xf).sum(dim=(0, 2, 3))
 
 
 def _t_apply(x, scale, shift, residual, relu):
-    y = x.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = _f(x) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if residual is not None:
-        y = y + residual.float()
+        y = y + _f(residual)
     if relu:
         y = torch.relu(y)
     return y.to(x.dtype)
 
 
 def _t_bwd_reduce(dy, x, y, mean, invstd, relu):
-    dyf = dy.float()
+    dyf = _f(dy)
     if relu:
         dyf = dyf * (y > 0)
-    xhat = (x.float() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    xhat = (_f(x) - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
     return dyf.sum(dim=(0, 2, 3)), (dyf * xhat).sum(dim=(0, 2, 3))
 
 
 def _t_bwd_apply(dy, x, y, mean, invstd, weight, sum_dy, sum_dy_xhat, count, relu, need_dres):
-    dyf = dy.float()
+    dyf = _f(dy)
     if relu:
         dyf = dyf * (y > 0)
     v = lambda t: t.view(1, -1, 1, 1)  # noqa: E731
-    xhat = (x.float() - v(mean)) * v(invstd)
+    xhat = (_f(x) - v(mean)) * v(invstd)
     dx = v(weight * invstd) * (dyf - v(sum_dy) / count - xhat * v(sum_dy_xhat) / count)
     dres = dyf.to(dy.dtype) if need_dres else None
     return dx.to(x.dtype), dres
@@ -198,8 +204,8 @@ class _BatchNormActTrain(torch.autograd.Function):
                     unbiased = var * (count / max(count - 1.0, 1.0))
                     running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
                     running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
-            w = weight.detach().float() if weight is not None else torch.ones_like(mean)
-            b = bias.detach().float() if bias is not None else torch.zeros_like(mean)
+            w = _f(weight.detach()) if weight is not None else torch.ones_like(mean)
+            b = _f(bias.detach()) if bias is not None else torch.zeros_like(mean)
             scale = w * invstd
             shift = b - mean * scale
             y = _t_apply(x, scale, shift, residual, relu)

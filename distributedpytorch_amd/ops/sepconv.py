@@ -54,7 +54,7 @@ class _FoldedPointwise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, gamma, beta, weight, stats1, w_lowp, bn1, bn2):
-        from . import _hip_bn, _hip_conv, workspace
+        from . import _hip_bn, _hip_conv
         n, cin, h, w = z.shape
         cout = weight.shape[0]
         count = float(n * h * w)
@@ -62,8 +62,9 @@ class _FoldedPointwise(torch.autograd.Function):
         wf, vec, _ = _hip_bn.fold_into_pointwise(stats1, g32, b32, bn1.running_mean, bn1.running_var, count, bn1.eps,
                                                  bn1.momentum, w_lowp, bn2.running_mean, bn2.momentum)
         reps = _hip_conv.stat_replicas(n * h * w)
-        stats2 = workspace.zeros(reps * 2 * cout, z.device).view(reps, 2, cout)
+        stats2 = _hip_conv.stats_buffer(reps, cout, z.device)
         y = _hip_conv.igemm(z, wf, (h, w), 1, 1, (0, 0), (1, 1), None, stats2)
+        stats2 = _hip_conv.fold_stats(stats2)
         ctx.save_for_backward(z, wf, w_lowp, vec, g32)
         ctx.params = (gamma, beta, weight)
         ctx.count = count

@@ -59,7 +59,9 @@ _dirty: Dict[int, bool] = {}
 
 
 def enabled() -> bool:
-    return _ENABLED
+    """Auxiliary stream in use?  Never in deterministic mode (ops._backend): one stream, one order."""
+    from . import _backend
+    return _ENABLED and not _backend.deterministic()
 
 
 def set_enabled(flag: bool) -> None:

@@ -221,24 +221,23 @@ def test_wgrad_splits(case, splits, wgrad_mfma):
 
 
 @pytest.fixture
-def dw_gen(request):
-    """Depthwise kernel generation for one test (csrc/depthwise.hip, dp_dwconv_set_gen); restored afterwards."""
+def dw_window(request):
+    """Rolling-window depthwise kernels on / off for one test (csrc/depthwise.hip, dp_dwconv_set_window); restored."""
     from distributedpytorch_amd.ops import _hip_conv
     lib = _hip_conv._lib()
-    old = lib.dp_dwconv_set_gen(request.param)
+    old = lib.dp_dwconv_set_window(request.param)
     yield request.param
-    lib.dp_dwconv_set_gen(old)
+    lib.dp_dwconv_set_window(old)
 
 
-@pytest.mark.parametrize("dw_gen", [4, 6], indirect=True)
+@pytest.mark.parametrize("dw_window", [1, 0], indirect=True)
 @pytest.mark.parametrize("stride,dil", [(1, 1), (1, 2), (2, 1), (1, 4)])
 @pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (1, 64, 7, 129), (1, 64, 9, 200),
                                    (5, 64, 3, 5)])
-def test_depthwise(stride, dil, shape, dw_gen):
-    """flat kernels (stride 2), the rolling-window kernels (stride 1: several bands per image, partial 64-channel
-    slab, one to four rows per step; generation 4 = packed dot products, 6 = forward / data gradient on the matrix
-    cores) and the row-tiled kernels behind them (maps wider than 160 columns) against an fp32 CPU grouped
-    convolution."""
+def test_depthwise(stride, dil, shape, dw_window):
+    """The rolling-window kernels (stride 1: several bands per image, column bands for maps wider than 160 columns,
+    partial 64-channel slab, one to four rows per step) and the general-shape kernels behind them (stride 2; every
+    shape with the window kernels switched off) against an fp32 CPU grouped convolution."""
     torch.manual_seed(1)
     n, c, h, w = shape
     x = _bf(torch.randn(n, c, h, w, device=DEV))
@@ -256,35 +255,6 @@ def test_depthwise(stride, dil, shape, dw_gen):
     yh.backward(_nhwc(gy))
     assert _rel(xh.grad, xr.grad) < 1.5e-2
     assert _rel(wh.grad, wr.grad) < 1.5e-2
-
-
-@pytest.mark.parametrize("dil", [1, 2])
-@pytest.mark.parametrize("shape", [(2, 72, 33, 31), (3, 136, 65, 65), (2, 728, 9, 65)])
-def test_depthwise_wgrad_on_matrix_cores(dil, shape):
-    """csrc/depthwise.hip dwconv5_wgrad_kernel (opt-in generation 5): the weight gradient as the diagonal of a
-    16x16 MFMA product over the pixel index — transposed LDS reads of the swizzled x / dy rings, overlapping last
-    chunk, partial 16-channel group — against an fp32 CPU grouped convolution."""
-    from distributedpytorch_amd.ops import _backend as B
-    from distributedpytorch_amd.ops import _hip_conv
-    torch.manual_seed(2)
-    n, c, h, w = shape
-    x = _bf(torch.randn(n, c, h, w, device=DEV))
-    xr = x.float().cpu()
-    wr = torch.zeros(c, 1, 3, 3, requires_grad=True)
-    yr = F.conv2d(xr, wr, None, 1, dil, dil, groups=c)
-    gy = _bf(torch.randn_like(yr)).to(DEV)
-    yr.backward(gy.float().cpu())
-    lib = _hip_conv._lib()
-    old = lib.dp_dwconv_set_gen(5)
-    try:
-        dw9 = torch.zeros(9, c, device=DEV)
-        gy_l, x_l = _nhwc(gy), _nhwc(x)              # named: the launcher takes raw pointers
-        B.check(lib.dp_dwconv_bwd_weight(B.ptr(gy_l), B.ptr(x_l), B.ptr(dw9), n, c, h, w, h, w, 1, dil, dil, dil,
-                                         B.stream_ptr()), "dwconv_bwd_weight")
-        torch.cuda.synchronize()
-    finally:
-        lib.dp_dwconv_set_gen(old)
-    assert _rel(dw9.t().reshape(c, 1, 3, 3), wr.grad) < 1e-2
 
 
 def test_conv_fused_statistics():

@@ -201,18 +201,8 @@ class _TinyXception(torch.nn.Module):
         return self.b3(self.b2(self.b1(x)))
 
 
-@pytest.fixture
-def dw_gen(request):
-    from distributedpytorch_amd.ops import _hip_conv
-    lib = _hip_conv._lib()
-    old = lib.dp_dwconv_set_gen(request.param)
-    yield request.param
-    lib.dp_dwconv_set_gen(old)
-
-
-@pytest.mark.parametrize("dw_gen", [4, 7], indirect=True)
 @pytest.mark.parametrize("stride", [1, 2])
-def test_xception_blocks_match_cpu_fp32(stride, dw_gen):
+def test_xception_blocks_match_cpu_fp32(stride):
     torch.manual_seed(5)
     net = _TinyXception(stride).train()
     with torch.no_grad():
