@@ -269,6 +269,9 @@ def main():
                                   lib_rebuilt_at_load=bi.get("rebuilt"), tile_table_entries=tr["packaged"],
                                   tiles_autotuned_in_run=tr["measured_here"],
                                   tile_table_hit=tr["measured_here"] == 0)
+            from distributedpytorch_amd.ops import bnfold
+            rec["runtime"]["bn3_fold_backwards"] = dict(bnfold.COUNTS)
+            rec["runtime"]["deterministic"] = _backend.deterministic()
         if on_gpu:
             base = load_self_baseline(args.model, S, B)
             if args.impl == "native" and base is not None:

@@ -589,6 +589,123 @@ __global__ void bn_fold_bwd_final_kernel(const float* __restrict__ ds, const flo
     if (dgamma_sink) dgamma_sink[j] += ds[j] * r * sink_scale;
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward folded into the gradients of the 1x1 convolution in front of it (ops/bnfold.py: the tail of a
+// ResNet bottleneck).  W: bf16 [K4][K1] weights, T = dm^T a (fp32 [K4][K1], from the weight-gradient kernel on the
+// masked gradient), part: [reps][2][K4] partial sums whose first row is Σdm.
+//   bn3fold_rows   sums[0][k] = Σdm_k,  sums[1][k] = Σ dm x̂ = rstd_k (Σ_j W_kj T_kj - mean_k Σdm_k)   (one wave per row)
+//   bn3fold_coef   ka = g rstd, kb = -ka rstd Σ(dm x̂) / M, kc = -ka Σdm / M - kb mean; Wf = fp32(W), KBW = kb W,
+//                  dgamma / dbeta sinks                                                                (one wave per row)
+//   bn3fold_comb   dW_sink += ka T + kb WA + kc s^T ; Gb = bf16(G) ; c0 = W^T kc ; WpT = bf16(W^T diag(ka))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn3fold_rows_kernel(const bf16_raw* __restrict__ W, const float* __restrict__ T,
+                                                           const float* __restrict__ part, int reps,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ sums, int K4, int K1) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K4) return;
+    float dot = 0.f;
+    for (int j = lane * 8; j < K1; j += 512) {
+        float w[8];
+        unpack8(*reinterpret_cast<const uint4*>(W + (long)k * K1 + j), w);
+        const float4 t0 = *reinterpret_cast<const float4*>(T + (long)k * K1 + j);
+        const float4 t1 = *reinterpret_cast<const float4*>(T + (long)k * K1 + j + 4);
+        dot = fmaf(w[0], t0.x, dot); dot = fmaf(w[1], t0.y, dot); dot = fmaf(w[2], t0.z, dot); dot = fmaf(w[3], t0.w, dot);
+        dot = fmaf(w[4], t1.x, dot); dot = fmaf(w[5], t1.y, dot); dot = fmaf(w[6], t1.z, dot); dot = fmaf(w[7], t1.w, dot);
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        float sdy = 0.f;
+        for (int r = 0; r < reps; ++r) sdy += part[(long)r * 2 * K4 + k];
+        sums[k] = sdy;
+        sums[K4 + k] = rstd[k] * (dot - mean[k] * sdy);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn3fold_coef_kernel(const bf16_raw* __restrict__ W, const float* __restrict__ sums,
+                                                           const float* __restrict__ lsums,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, float inv_m, float sink_scale,
+                                                           float* __restrict__ Wf, float* __restrict__ KBW,
+                                                           float* __restrict__ kvec,
+                                                           float* __restrict__ dgamma_sink, float* __restrict__ dbeta_sink,
+                                                           int K4, int K1) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K4) return;
+    const float sdy = sums[k], sdyx = sums[K4 + k];
+    const float ka = (gamma ? gamma[k] : 1.f) * rstd[k];
+    const float kb = -ka * rstd[k] * sdyx * inv_m;
+    const float kc = -ka * sdy * inv_m - kb * mean[k];
+    if (lane == 0) {
+        kvec[k] = ka; kvec[K4 + k] = kb; kvec[2 * K4 + k] = kc;
+        // column K1 of the [K4][K1 + 8] matrix KBW holds kc: the GEMM G' = Wf^T KBW then delivers c0 = W^T kc as its
+        // column K1 (a loop over k in one block took 200 us)
+        *reinterpret_cast<float4*>(KBW + (long)k * (K1 + 8) + K1) = make_float4(kc, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(KBW + (long)k * (K1 + 8) + K1 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        // affine gradients from the sums in `lsums` (local, or the all-reduced ones with sink_scale = 1 / world)
+        if (dgamma_sink) dgamma_sink[k] += lsums[K4 + k] * sink_scale;
+        if (dbeta_sink) dbeta_sink[k] += lsums[k] * sink_scale;
+    }
+    for (int j = lane * 8; j < K1; j += 512) {
+        float w[8];
+        unpack8(*reinterpret_cast<const uint4*>(W + (long)k * K1 + j), w);
+        float4 a0 = make_float4(w[0], w[1], w[2], w[3]), a1 = make_float4(w[4], w[5], w[6], w[7]);
+        *reinterpret_cast<float4*>(Wf + (long)k * K1 + j) = a0;
+        *reinterpret_cast<float4*>(Wf + (long)k * K1 + j + 4) = a1;
+        *reinterpret_cast<float4*>(KBW + (long)k * (K1 + 8) + j) = make_float4(kb * w[0], kb * w[1], kb * w[2], kb * w[3]);
+        *reinterpret_cast<float4*>(KBW + (long)k * (K1 + 8) + j + 4) = make_float4(kb * w[4], kb * w[5], kb * w[6], kb * w[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn3fold_comb_kernel(const float* __restrict__ T, const float* __restrict__ WA,
+                                                           const float* __restrict__ s, const float* __restrict__ kvec,
+                                                           const float* __restrict__ Wf, const float* __restrict__ G,
+                                                           float* __restrict__ dw_sink, bf16_raw* __restrict__ Gb,
+                                                           float* __restrict__ c0, const bf16_raw* __restrict__ WT,
+                                                           bf16_raw* __restrict__ WpT, int K4, int K1, int blocks_dw,
+                                                           int blocks_g, int blocks_t) {
+    const int b = blockIdx.x;
+    if (b < blocks_dw) {
+        // dW[k][j] += ka_k T + kb_k WA + kc_k s_j : 4 consecutive elements per thread
+        const long i4 = ((long)b * 256 + threadIdx.x) * 4;
+        if (i4 < (long)K4 * K1) {
+            const int k = (int)(i4 / K1), j = (int)(i4 - (long)k * K1);
+            const float ka = kvec[k], kb = kvec[K4 + k], kc = kvec[2 * K4 + k];
+            const float4 t = *reinterpret_cast<const float4*>(T + i4);
+            const float4 wa = *reinterpret_cast<const float4*>(WA + i4);
+            const float4 sv = *reinterpret_cast<const float4*>(s + j);
+            float4 d = *reinterpret_cast<float4*>(dw_sink + i4);
+            d.x += fmaf(ka, t.x, fmaf(kb, wa.x, kc * sv.x));
+            d.y += fmaf(ka, t.y, fmaf(kb, wa.y, kc * sv.y));
+            d.z += fmaf(ka, t.z, fmaf(kb, wa.z, kc * sv.z));
+            d.w += fmaf(ka, t.w, fmaf(kb, wa.w, kc * sv.w));
+            *reinterpret_cast<float4*>(dw_sink + i4) = d;
+        }
+    } else if (b < blocks_dw + blocks_g) {
+        // G' is [K1][K1 + 8]: columns 0 .. K1-1 -> Gb (bf16), column K1 -> c0
+        const long i = ((long)(b - blocks_dw) * 256 + threadIdx.x) * 2;
+        if (i < (long)K1 * K1) {
+            const int r = (int)(i / K1), c = (int)(i - (long)r * K1);
+            const float2 g = *reinterpret_cast<const float2*>(G + (long)r * (K1 + 8) + c);
+            *reinterpret_cast<unsigned*>(Gb + i) = pack2(g.x, g.y);
+            if (c == 0) c0[r] = G[(long)r * (K1 + 8) + K1];
+        }
+    } else if (b < blocks_dw + blocks_g + blocks_t) {
+        // WpT[j][k] = ka_k WT[j][k]: the data gradient's weights (W^T with its columns scaled), 8 elements per thread
+        const long i8 = ((long)(b - blocks_dw - blocks_g) * 256 + threadIdx.x) * 8;
+        if (i8 < (long)K1 * K4) {
+            const int k = (int)(i8 % K4);
+            float w[8];
+            unpack8(*reinterpret_cast<const uint4*>(WT + i8), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] *= kvec[k + e];
+            *reinterpret_cast<uint4*>(WpT + i8) = pack8(w);
+        }
+    }
+}
+
 // set by dp_bn_set_dropout for the NEXT apply_stats / bwd_reduce / bwd_apply launch of this thread
 thread_local Drop t_drop = {0u, 1.f, 0u, 0u};
 
@@ -777,5 +894,48 @@ DP_EXPORT int dp_bn_fold_bwd(const float* dwf, const void* w, const float* s, co
                        (const bf16_raw*)w, s, dw_sink, ds, Cout, Cin, sink_scale);
     hipLaunchKernelGGL(bn_fold_bwd_final_kernel, dim3((Cin + 255) / 256), dim3(256), 0, st, ds, gamma, rstd, mean, cvec,
                        cshift, dgamma_sink, 1.f / count, sink_scale, Cin);
+    return DP_LAUNCH_STATUS();
+}
+
+// ops/bnfold.py, step 1: sums fp32 [2][K4] = (Σdm, Σ dm·x̂).  K1 % 8 == 0.
+DP_EXPORT int dp_bn3fold_rows(const void* W, const float* T, const float* part, int reps, const float* mean,
+                              const float* rstd, float* sums, int K4, int K1, hipStream_t st) {
+    if (!W || !T || !part || !mean || !rstd || !sums || reps < 1 || K4 <= 0 || K1 <= 0 || K1 % 8 != 0) return -1;
+    if (((uintptr_t)W | (uintptr_t)T) & 15) return -3;
+    hipLaunchKernelGGL(bn3fold_rows_kernel, dim3((K4 + 3) / 4), dim3(256), 0, st, (const bf16_raw*)W, T, part, reps,
+                       mean, rstd, sums, K4, K1);
+    return DP_LAUNCH_STATUS();
+}
+
+// step 2: coefficients and operand matrices.  Wf fp32 [K4][K1]; KBW fp32 [K4][K1 + 8] = kb W | kc | 0;
+// kvec fp32 [3][K4] = ka | kb | kc.
+// lsums: the sums the affine gradients are formed from (== sums, or local / global as the caller decides).
+DP_EXPORT int dp_bn3fold_coef(const void* W, const float* sums, const float* lsums, const float* mean,
+                              const float* rstd, const float* gamma, float inv_m, float sink_scale, float* Wf,
+                              float* KBW, float* kvec, float* dgamma_sink, float* dbeta_sink, int K4, int K1,
+                              hipStream_t st) {
+    if (!W || !sums || !lsums || !mean || !rstd || !Wf || !KBW || !kvec || K4 <= 0 || K1 <= 0 || K1 % 8 != 0)
+        return -1;
+    if (((uintptr_t)W | (uintptr_t)Wf | (uintptr_t)KBW) & 15) return -3;
+    hipLaunchKernelGGL(bn3fold_coef_kernel, dim3((K4 + 3) / 4), dim3(256), 0, st, (const bf16_raw*)W, sums, lsums, mean,
+                       rstd, gamma, inv_m, sink_scale, Wf, KBW, kvec, dgamma_sink, dbeta_sink, K4, K1);
+    return DP_LAUNCH_STATUS();
+}
+
+// step 3 (after WA = Wf A and G' = Wf^T KBW, [K1][K1 + 8]): dw_sink += ka T + kb WA + kc s^T; Gb = bf16(G'[:, :K1]);
+// c0 = G'[:, K1];
+// WpT bf16 [K1][K4] = WT (the bf16 transposed weights [K1][K4]) with column k scaled by ka_k.  K4 % 8 == 0.
+DP_EXPORT int dp_bn3fold_comb(const float* T, const float* WA, const float* s, const float* kvec, const float* Wf,
+                              const float* G, float* dw_sink, void* Gb, float* c0, const void* WT, void* WpT, int K4,
+                              int K1, hipStream_t st) {
+    if (!T || !WA || !s || !kvec || !Wf || !G || !dw_sink || !Gb || !c0 || !WT || !WpT || K4 <= 0 || K1 <= 0 ||
+        K1 % 8 != 0 || K4 % 8 != 0)
+        return -1;
+    if (((uintptr_t)T | (uintptr_t)WA | (uintptr_t)s | (uintptr_t)dw_sink | (uintptr_t)G | (uintptr_t)WT | (uintptr_t)WpT) & 15)
+        return -3;
+    const int bdw = (int)(((long)K4 * K1 / 4 + 255) / 256), bg = (int)(((long)K1 * K1 / 2 + 255) / 256);
+    const int bt = (int)(((long)K1 * K4 / 8 + 255) / 256);
+    hipLaunchKernelGGL(bn3fold_comb_kernel, dim3(bdw + bg + bt), dim3(256), 0, st, T, WA, s, kvec, Wf, G, dw_sink,
+                       (bf16_raw*)Gb, c0, (const bf16_raw*)WT, (bf16_raw*)WpT, K4, K1, bdw, bg, bt);
     return DP_LAUNCH_STATUS();
 }

@@ -51,7 +51,9 @@ struct Conv2Args {
     // differentiates, a = relu(BN(bnx) [+ identity]), is the previous layer's activation; instead of
     // da the store loop writes dm = da·[a > 0] and accumulates Σdm, Σdm·x̂ per channel — the two
     // reductions BN backward needs — so the separate bn_bwd_reduce pass (dy, x, y re-read) is gone.
-    const bf16_raw* bnx;    // [M, Cout] pre-BN activations (x̂ = (bnx − mean)·rstd) or null
+    const bf16_raw* bnx;    // [M, Cout] pre-BN activations (x̂ = (bnx − mean)·rstd); null with bnsums given: mask and Σdm
+                            //   only (ops.bnfold: Σdm·x̂ of a BatchNorm behind a 1x1 convolution comes out of that
+                            //   convolution's weight gradient, so the pre-BN tensor is not read here at all)
     const bf16_raw* bna;    // [M, Cout] a itself (mask source) or null: mask = bnx·scale + shift > 0
     const unsigned char* bnmask;   // [M, Cout/8] positivity bits of a (bn_relu.hip, ApplyArgs::mask): the mask source
                             //   of a residual block's output at 1/16 of the bytes of bna; takes precedence over bna
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
         constexpr int RPP = T / TPR;              // rows per pass
         const int cpiece = tid % TPR, rsub = tid / TPR;
         const int gcol = n0 + cpiece * 8;
-        if (p.bnx == nullptr) {
+        if (p.bnsums == nullptr) {
             float rsc[8], rsh[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             // restrict-qualified locals + a batch of GRP rows per round: all global loads of a round
             // are issued before the first is consumed (the store loop is otherwise one exposed memory
             // round trip per row)
-            const bf16_raw* __restrict__ bnx = p.bnx;
+            const bf16_raw* __restrict__ bnx = p.bnx;          // may be null (mask + Σdm only)
             const unsigned char* __restrict__ bnm = p.bnmask;
             const bf16_raw* __restrict__ bna = bnm ? nullptr : p.bna;
             const bf16_raw* __restrict__ resp = p.res;
@@ -601,8 +603,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             float mu[8], is[8], sc[8], sh[8], s1[8], s2[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                mu[j] = col_ok ? p.bn_mean[gcol + j] : 0.f;
-                is[j] = col_ok ? p.bn_rstd[gcol + j] : 0.f;
+                mu[j] = col_ok && bnx ? p.bn_mean[gcol + j] : 0.f;
+                is[j] = col_ok && bnx ? p.bn_rstd[gcol + j] : 0.f;
                 sc[j] = (col_ok && p.bn_w ? p.bn_w[gcol + j] : 1.f) * is[j];
                 sh[j] = fmaf(-mu[j], sc[j], col_ok && p.bn_b ? p.bn_b[gcol + j] : 0.f);
                 s1[j] = 0.f; s2[j] = 0.f;
@@ -623,7 +625,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                     const int m = m0 + r0 + g * RPP + rsub;
                     ok[g] = (m < p.M) && col_ok;
                     off[g] = (long)min(m, p.M - 1) * p.Cout + gcl;
-                    vx[g] = *reinterpret_cast<const uint4*>(bnx + off[g]);
+                }
+                if (bnx) {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) vx[g] = *reinterpret_cast<const uint4*>(bnx + off[g]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < GRP; ++g) vx[g] = make_uint4(0, 0, 0, 0);
                 }
                 if (bna) {
 #pragma unroll
@@ -834,7 +842,7 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return -3;
     const int ldx = t_ldx > 0 ? t_ldx : Cin;
     if (ldx > Cin || (ldx % 8 != 0 && ldx != 4)) return -1;
-    if (ldx != Cin && (S != 1 || res || t_bnx || sdiv != 1)) return -1;   // windows overlap along W only
+    if (ldx != Cin && (S != 1 || res || t_bnsums || sdiv != 1)) return -1;   // windows overlap along W only
     const long x_bytes = (long)N * Hi * Wi * ldx * 2, w_bytes = (long)Cout * R * S * Cin * 2;
     // 32-bit byte offsets below the out-of-range marker, with room for the largest tap offset
     if (x_bytes >= (1L << 31) - (1L << 24) || w_bytes >= (1L << 31) - (1L << 24) || (long)N * Ho * Wo >= (1L << 31) - 512)
@@ -843,12 +851,13 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.x = (const bf16_raw*)x; p.w = (const bf16_raw*)w; p.y = (bf16_raw*)y; p.bias = bias; p.stats = stats;
     p.res = (const bf16_raw*)res; p.ldres = ldres;
     p.res_scale = res ? t_res_affine[0] : nullptr; p.res_shift = res ? t_res_affine[1] : nullptr;
-    if (p.res_scale && t_bnx) return -1;
+    if (p.res_scale && t_bnsums) return -1;
     p.bnx = (const bf16_raw*)t_bnx; p.bna = (const bf16_raw*)t_bna; p.bnsums = t_bnsums;
     p.bnmask = (const unsigned char*)t_bnmask;
     p.bn_mean = t_bnp[0]; p.bn_rstd = t_bnp[1]; p.bn_w = t_bnp[2]; p.bn_b = t_bnp[3];
     p.bn_reps = t_bn_reps < 1 ? 1 : t_bn_reps;
-    if (p.bnx && (stats || bias || ldy != Cout)) return -1;
+    if (p.bnsums && (stats || ldy != Cout)) return -1;
+    if (p.bnsums && !p.bnx && !p.bnmask && !p.bna) return -1;      // no pre-BN tensor: the mask needs a source
     p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
     p.M = (int)((long)N * Ho * Wo);
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
@@ -905,7 +914,8 @@ DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int 
                               int dil_w, int cfg, const void* res, const void* bnx, const void* bna,
                               const void* bnmask, const float* bn_mean, const float* bn_rstd, const float* bn_w,
                               const float* bn_b, float* bnsums, int bn_reps, hipStream_t st) {
-    if (!bnx || !bn_mean || !bn_rstd || !bnsums || bn_reps < 1) return -1;
+    if (!bnsums || bn_reps < 1 || (bnx && (!bn_mean || !bn_rstd))) return -1;
+    if (!bnx && !bnmask && !bna) return -1;
     if (((uintptr_t)bnx | (uintptr_t)bna) & 15) return -3;
     t_bnmask = bnmask;
     t_bnx = bnx; t_bna = bna; t_bnsums = bnsums; t_bn_reps = bn_reps;

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from ..ops import conv_bn_act, BatchNorm2d, Conv2d, MaxPool3x3s2
+from ..ops.bnfold import conv_bn_add_relu
 
 
 class _Projection(nn.Module):
@@ -89,6 +90,10 @@ class BasicBlock(_FanOutMixin, nn.Module):
 class Bottleneck(_FanOutMixin, nn.Module):
     expansion = 4
     input_exclusive = False      # see BasicBlock
+    # set by ResNet: the block's output feeds a convolution that runs this block's ReLU mask and Σdm in its
+    # data-gradient store loop (the next block's conv1) -> the last BatchNorm's backward is folded into conv3's
+    # gradients (ops.bnfold) and the 4x-wide pre-BN tensor is neither kept nor re-read in backward
+    fold_tail = False
 
     def __init__(self, cin: int, planes: int, stride: int = 1, dilation: int = 1,
                  downsample: Optional[nn.Module] = None):
@@ -110,6 +115,8 @@ class Bottleneck(_FanOutMixin, nn.Module):
         else:
             out, identity = self._projected(x)
         out = conv_bn_act(self.conv2, self.bn2, out, relu=True, sole_consumer=True)
+        if self.fold_tail:
+            return conv_bn_add_relu(self.conv3, self.bn3, out, identity, sole_consumer=True)
         return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity, sole_consumer=True)
 
 
@@ -156,6 +163,10 @@ class ResNet(nn.Module):
         self.layer4 = self._stage(block, 512, depths[3], strides[3], dilations[3], grid)
         self.out_channels = 512 * block.expansion
         self.low_level_channels = 64 * block.expansion
+        if block is Bottleneck:
+            chain = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+            for b in chain[:-1]:             # (the last block's output goes to a head with several consumers)
+                b.fold_tail = True
         for m in self.modules():
             if isinstance(m, BatchNorm2d):
                 nn.init.ones_(m.weight)

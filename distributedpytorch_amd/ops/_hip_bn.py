@@ -33,6 +33,9 @@ def _lib():
         lib.dp_bn_fold.argtypes = [c_void_p, c_int, c_long] + [c_void_p] * 4 + [c_float] * 3 + [c_void_p] * 7 + \
             [c_float, c_int, c_int, c_void_p]
         lib.dp_bn_fold_bwd.argtypes = [c_void_p] * 11 + [c_float, c_float, c_int, c_int, c_void_p]
+        lib.dp_bn3fold_rows.argtypes = [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]
+        lib.dp_bn3fold_coef.argtypes = [c_void_p] * 6 + [c_float, c_float] + [c_void_p] * 5 + [c_int, c_int, c_void_p]
+        lib.dp_bn3fold_comb.argtypes = [c_void_p] * 11 + [c_int, c_int, c_void_p]
         _sigs_done = True
     return lib
 
@@ -291,3 +294,56 @@ def affine_add_(acc, x, scale, shift):
     B.check(_lib().dp_bn_apply_affine(B.ptr(x), B.ptr(acc), B.ptr(acc), M, C, B.ptr(scale), B.ptr(shift), 0,
                                       B.stream_ptr()), "bn_apply_affine")
     return acc
+
+
+# ------------------------------------------------------------------ BatchNorm backward folded into a 1x1 convolution
+def bn3fold_rows(w_lowp, T, part, mean, rstd):
+    """sums fp32 [2, K4] = (Σdm, Σ dm·x̂) from the weight gradient T = dmᵀ a (csrc/bn_relu.hip, bn3fold_rows)."""
+    k4, k1 = w_lowp.shape[:2]
+    if (w_lowp.dtype != torch.bfloat16 or T.dtype != torch.float32 or T.numel() != k4 * k1 or not T.is_contiguous()
+            or part.dtype != torch.float32 or part.dim() != 3 or tuple(part.shape[1:]) != (2, k4)
+            or not part.is_contiguous() or k1 % 8):
+        raise ValueError("bn3fold_rows: W bf16 [K4, K1, 1, 1], T fp32 [K4, K1], part fp32 [R, 2, K4]")
+    _check_vec(mean, k4, "mean"); _check_vec(rstd, k4, "rstd")
+    sums = torch.empty(2, k4, dtype=torch.float32, device=T.device)
+    B.check(_lib().dp_bn3fold_rows(B.ptr(w_lowp), B.ptr(T), B.ptr(part), int(part.shape[0]), B.ptr(mean), B.ptr(rstd),
+                                   B.ptr(sums), k4, k1, B.stream_ptr()), "bn3fold_rows")
+    return sums
+
+
+def bn3fold_coef(w_lowp, sums, lsums, mean, rstd, gamma, count, sink_scale, dgamma_sink, dbeta_sink):
+    """(Wf fp32 [K4, K1], KBW fp32 [K4, K1 + 8] = kb W | kc | 0, kvec fp32 [3, K4] = ka | kb | kc); adds the affine
+    gradients into the sinks when given."""
+    k4, k1 = w_lowp.shape[:2]
+    for t in (sums, lsums):
+        if t.dtype != torch.float32 or tuple(t.shape) != (2, k4) or not t.is_contiguous():
+            raise ValueError("bn3fold_coef: sums fp32 [2, K4]")
+    for t, nm in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (dgamma_sink, "dgamma_sink"), (dbeta_sink, "dbeta_sink")):
+        _check_vec(t, k4, nm)
+    dev = w_lowp.device
+    wf = torch.empty(k4, k1, dtype=torch.float32, device=dev)
+    kbw = torch.empty(k4, k1 + 8, dtype=torch.float32, device=dev)      # kb W | kc | 0 (csrc/bn_relu.hip)
+    kvec = torch.empty(3, k4, dtype=torch.float32, device=dev)
+    B.check(_lib().dp_bn3fold_coef(B.ptr(w_lowp), B.ptr(sums), B.ptr(lsums), B.ptr(mean), B.ptr(rstd), B.ptr(gamma),
+                                   1.0 / float(count), float(sink_scale), B.ptr(wf), B.ptr(kbw), B.ptr(kvec),
+                                   B.ptr(dgamma_sink), B.ptr(dbeta_sink), k4, k1, B.stream_ptr()), "bn3fold_coef")
+    return wf, kbw, kvec
+
+
+def bn3fold_comb(T, WA, s, kvec, wf, G, dw_sink, wT):
+    """dw_sink += ka T + kb WA + kc sᵀ; returns (Gb bf16 [K1, K1, 1, 1], c0 fp32 [K1], WpT bf16 [K1, K4, 1, 1])."""
+    k4, k1 = wf.shape
+    for t, shp, nm in ((T, k4 * k1, "T"), (WA, k4 * k1, "WA"), (G, k1 * (k1 + 8), "G"), (dw_sink, k4 * k1, "dw_sink")):
+        if t.dtype != torch.float32 or t.numel() != shp or \
+                not (t.is_contiguous() or (t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous())):
+            raise ValueError(f"bn3fold_comb: {nm} must be dense fp32 with {shp} elements")
+    _check_vec(s, k1, "s")
+    if wT.dtype != torch.bfloat16 or wT.numel() != k4 * k1 or k4 % 8:
+        raise ValueError("bn3fold_comb: wT bf16 [K1, K4, 1, 1]")
+    dev = wf.device
+    gb = torch.empty((k1, k1, 1, 1), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    wpt = torch.empty((k1, k4, 1, 1), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    c0 = torch.empty(k1, dtype=torch.float32, device=dev)
+    B.check(_lib().dp_bn3fold_comb(B.ptr(T), B.ptr(WA), B.ptr(s), B.ptr(kvec), B.ptr(wf), B.ptr(G), B.ptr(dw_sink),
+                                   B.ptr(gb), B.ptr(c0), B.ptr(wT), B.ptr(wpt), k4, k1, B.stream_ptr()), "bn3fold_comb")
+    return gb, c0, wpt

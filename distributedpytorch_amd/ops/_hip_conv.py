@@ -259,9 +259,14 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
     n, cin, hi, wi = dy.shape
     cout, cin_w, r, s = wt.shape
     ho, wo = out_hw
-    bx = holder["x"]
-    if (cin != cin_w or cin % 8 or cout % 8 or tuple(bx.shape) != (n, cout, ho, wo) or bx.dtype != torch.bfloat16
-            or not bx.is_contiguous(memory_format=torch.channels_last)):
+    bx = holder.get("x")              # None: mask and Σdm only (ops.bnfold: Σdm·x̂ comes out of a weight gradient)
+    shape = (n, cout, ho, wo)
+    if cin != cin_w or cin % 8 or cout % 8:
+        return None
+    if bx is not None and (tuple(bx.shape) != shape or bx.dtype != torch.bfloat16
+                           or not bx.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    if bx is None and not holder.get("mask_from_a"):
         return None
     ba = a if holder.get("mask_from_a") else None      # the activation itself = this convolution's input
     bits = holder.get("mask_bits") if holder.get("mask_from_a") else None
@@ -272,9 +277,9 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
         ba = None
     elif holder.get("mask_from_a") and ba is None:
         return None
-    if ba is not None and (ba.shape != bx.shape or not ba.is_contiguous(memory_format=torch.channels_last)):
+    if ba is not None and (tuple(ba.shape) != shape or not ba.is_contiguous(memory_format=torch.channels_last)):
         return None
-    if residual is not None and (residual.shape != bx.shape or residual.dtype != torch.bfloat16
+    if residual is not None and (tuple(residual.shape) != shape or residual.dtype != torch.bfloat16
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         return None
     for nm in ("mean", "invstd", "w", "b"):
@@ -284,7 +289,7 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
     # the fused store loop is heavier than the plain one (it reads x and the mask source): its best tile is
     # measured on the fused launch itself
     key = ("dgrad_bn", n, hi, wi, cin, ho, wo, cout, r, s, sdiv, tuple(pad), tuple(dil), residual is not None,
-           ba is not None or bits is not None)
+           ba is not None or bits is not None) + (("nox",) if bx is None else ())
     cfg = _FORCED_CFG if _FORCED_CFG is not None else _TUNED.get(key)
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     reps = stat_replicas(n * ho * wo)
@@ -300,8 +305,8 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
             mask = bits.view(-1)[n0 * bits_img:] if bits is not None else None
             st = _lib().dp_conv_igemm2b(B.ptr(dy[n0:n1]), B.ptr(wt), B.ptr(y[n0:n1]), n1 - n0, hi, wi, cin, ho, wo, cout,
                                         r, s, 1, sdiv, pad[0], pad[1], dil[0], dil[1], c, B.ptr(sl(residual)),
-                                        B.ptr(bx[n0:n1]), B.ptr(sl(ba)), B.ptr(mask), B.ptr(holder["mean"]),
-                                        B.ptr(holder["invstd"]), B.ptr(holder.get("w")), B.ptr(holder.get("b")),
+                                        B.ptr(sl(bx)), B.ptr(sl(ba)), B.ptr(mask), B.ptr(holder.get("mean")),
+                                        B.ptr(holder.get("invstd")), B.ptr(holder.get("w")), B.ptr(holder.get("b")),
                                         sums_ptr, reps, stream)
             if st != 0:
                 break
@@ -750,7 +755,8 @@ class _DepthwiseConv(torch.autograd.Function):
         ctx.geom = (stride, padding, dilation, (hi, wi), (ho, wo))
         ctx.weight_param = weight
         ctx.passthrough = passthrough
-        ctx.bn_holder = bn_holder if (bn_holder and "x" in bn_holder) else None
+        # (a holder without the pre-BN tensor, ops.bnfold, is served by the dense kernels only)
+        ctx.bn_holder = bn_holder if (bn_holder and bn_holder.get("x") is not None) else None
         outs = [y]
         if with_stats:
             if stats is None:

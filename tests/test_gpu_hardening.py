@@ -422,3 +422,73 @@ def test_deterministic_mode_training_step_is_bit_identical(name, kwargs, size):
     assert all(torch.isfinite(a).all() for a in l1)
     bad = [i for i, (a, b) in enumerate(zip(p1, p2)) if not torch.equal(a, b)]
     assert not bad, f"{len(bad)} of {len(p1)} parameters differ between two deterministic runs"
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_bottleneck_tail_fold_matches_fp32_cpu(stride):
+    """ops.bnfold: the last BatchNorm of a bottleneck folded into conv3's gradients (T = dm^T a2, A = a2^T a2,
+    G = W^T diag(kb) W; the pre-BN tensor is neither kept nor read in backward).  Three bottlenecks (the first with a
+    projection shortcut) against the same modules in fp32 on the CPU, and against the unfolded kernels."""
+    from distributedpytorch_amd.models.resnet import Bottleneck, _Projection
+    from distributedpytorch_amd.ops import bnfold
+    torch.manual_seed(11)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = ops.Conv2d(16, 64, 3, padding=1, bias=False); self.sbn = ops.BatchNorm2d(64)
+            self.b0 = Bottleneck(64, 32, stride, 1, _Projection(64, 128, stride))
+            self.b1 = Bottleneck(128, 32, 1, 2)
+            self.b2 = Bottleneck(128, 32, 1, 1)
+            self.b1.input_exclusive = self.b2.input_exclusive = True
+            self.b0.fold_tail = self.b1.fold_tail = True        # b2's output goes to the loss: not folded
+            self.head = ops.Conv2d(128, 8, 1)
+
+        def forward(self, x):
+            x = ops.conv_bn_act(self.stem, self.sbn, x, relu=True)
+            return self.head(self.b2(self.b1(self.b0(x))))
+
+    net = _randomise_bn(Net()).train()
+    x = torch.randn(4, 16, 33, 31).to(torch.bfloat16)
+    ref = copy.deepcopy(net).float()
+    with torch.no_grad():
+        for p_ in ref.parameters():
+            if p_.dim() == 4:
+                p_.copy_(p_.to(torch.bfloat16).float())
+    yr = ref(x.float())
+    gy = torch.randn_like(yr).to(torch.bfloat16)
+    yr.backward(gy.float())
+    gref = {k: p_.grad for k, p_ in ref.named_parameters()}
+    res = {}
+    bnfold.COUNTS.update(folded=0, fallback=0)
+    for tag, on in (("fold", True), ("plain", False)):
+        old = bnfold._ENABLED
+        bnfold._ENABLED = on
+        try:
+            g = copy.deepcopy(net).to(DEV)
+            xi = _nhwc(x.to(DEV)).requires_grad_(True)
+            y = g(xi)
+            y.backward(_nhwc(gy.to(DEV)))
+            torch.cuda.synchronize()
+            res[tag] = (y.detach().float().cpu(), xi.grad.float().cpu(),
+                        {k: p_.grad.detach().float().cpu() for k, p_ in g.named_parameters()},
+                        {k: b.detach().float().cpu() for k, b in g.named_buffers()})
+        finally:
+            bnfold._ENABLED = old
+    assert bnfold.COUNTS == {"folded": 2, "fallback": 0}, bnfold.COUNTS
+    yf, dxf, gf, bf_ = res["fold"]
+    yp, dxp, gp, bp = res["plain"]
+    assert cosine(yf, yp) > 0.99999                         # the forward kernels are the same
+    for k in bf_:
+        assert torch.allclose(bf_[k], bp[k], rtol=1e-4, atol=1e-3), k       # running statistics
+    assert cosine(yf, yr) > 0.9995
+    worst = {}
+    for k in gref:
+        cf, cp = cosine(gf[k], gref[k]), cosine(gp[k], gref[k])
+        worst[k] = (cf, cp)
+        # the folded gradients are as close to fp32 as the unfolded ones
+        assert cf > 0.97 and cf > cp - 0.004, (k, cf, cp)
+        rf = float((gf[k] - gref[k]).norm() / gref[k].norm().clamp_min(1e-12))
+        rp = float((gp[k] - gref[k]).norm() / gref[k].norm().clamp_min(1e-12))
+        assert rf < max(1.5 * rp, rp + 0.02), (k, rf, rp)
+    assert cosine(dxf, dxp) > 0.995
