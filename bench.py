@@ -224,6 +224,17 @@ def main():
     elapsed = dist_env.all_reduce_scalar(elapsed, "max", info.device if on_gpu else None)
     final_loss = float(loss.item())
     phases = engine.timer.summary()
+    # one more step OUTSIDE the timed region with the per-bucket timeline on (parallel.ddp.profile_next_step): when
+    # each bucket could start, when it was done, when backward ended — which collective is exposed, and by how much
+    comm_prof = None
+    if on_gpu and engine.ddp._comm:
+        engine.ddp.profile_next_step()
+        one_step()
+        sync()
+        comm_prof = engine.ddp.comm_profile()
+        if comm_prof is not None:
+            comm_prof["exposed_after_backward_ms_max_over_ranks"] = round(dist_env.all_reduce_scalar(
+                comm_prof["exposed_after_backward_ms"], "max", info.device), 3)
     # exposed communication = what the step's stream waited for in finish_gradient_sync (HIP events), worst rank
     comm_wait = dist_env.all_reduce_scalar(phases.get("comm_wait", 0.0), "max", info.device if on_gpu else None)
     devices = [info.device.index if on_gpu else -1]
@@ -258,6 +269,8 @@ def main():
                      "exposed_comm_ms": round(comm_wait, 3)},
             "runtime": {"ops_backend": ops.get_backend()},
         }
+        if comm_prof is not None:
+            rec["comm"]["timeline_rank0"] = comm_prof
         mid = getattr(getattr(model, "backbone", None), "mid_physical", None)
         if mid is not None:     # Xception-65: the 728-channel flow stored 768 wide (zero padding channels, same network)
             rec["config"]["mid_channels"] = {"logical": 728, "stored": mid}

@@ -885,15 +885,22 @@ DP_EXPORT int dp_bn_fold(const float* stats, int nrep, long rep_stride, const fl
 
 // dwf fp32 [Cout][Cin] (weight gradient w.r.t. the folded weights); dw_sink fp32 [Cout][Cin] accumulated;
 // ds fp32 [Cin] zero-initialised scratch; cvec / cshift fp32 [Cin] outputs; dgamma_sink fp32 [Cin] accumulated or null
+// stage: 0 = both kernels; 1 = the weight pass only (dw_sink, ds); 2 = the final pass only (ds -> cvec, cshift,
+// dgamma_sink) — synchronised statistics all-reduce ds between the two.  `sink_scale` scales what goes into the
+// sinks of THAT stage (the weight gradient is local, dgamma under SyncBN is the global sum / world).
 DP_EXPORT int dp_bn_fold_bwd(const float* dwf, const void* w, const float* s, const float* gamma, const float* rstd,
                              const float* mean, float* dw_sink, float* ds, float* cvec, float* cshift,
-                             float* dgamma_sink, float count, float sink_scale, int Cout, int Cin, hipStream_t st) {
-    if (!dwf || !w || !s || !rstd || !mean || !dw_sink || !ds || !cvec || !cshift || Cin <= 0 || Cout <= 0 || count <= 0.f)
+                             float* dgamma_sink, float count, float sink_scale, int Cout, int Cin, int stage,
+                             hipStream_t st) {
+    if (!dwf || !w || !s || !rstd || !mean || !dw_sink || !ds || !cvec || !cshift || Cin <= 0 || Cout <= 0 || count <= 0.f ||
+        stage < 0 || stage > 2)
         return -1;
-    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((Cin + 63) / 64, g_dp_deterministic ? 1 : (Cout + 63) / 64), dim3(256), 0, st, dwf,
-                       (const bf16_raw*)w, s, dw_sink, ds, Cout, Cin, sink_scale);
-    hipLaunchKernelGGL(bn_fold_bwd_final_kernel, dim3((Cin + 255) / 256), dim3(256), 0, st, ds, gamma, rstd, mean, cvec,
-                       cshift, dgamma_sink, 1.f / count, sink_scale, Cin);
+    if (stage != 2)
+        hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((Cin + 63) / 64, g_dp_deterministic ? 1 : (Cout + 63) / 64), dim3(256), 0, st,
+                           dwf, (const bf16_raw*)w, s, dw_sink, ds, Cout, Cin, stage == 1 ? 1.f : sink_scale);
+    if (stage != 1)
+        hipLaunchKernelGGL(bn_fold_bwd_final_kernel, dim3((Cin + 255) / 256), dim3(256), 0, st, ds, gamma, rstd, mean, cvec,
+                           cshift, dgamma_sink, 1.f / count, sink_scale, Cin);
     return DP_LAUNCH_STATUS();
 }
 

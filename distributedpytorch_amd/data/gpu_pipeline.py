@@ -175,6 +175,29 @@ class GpuBatchLoader:
         if hasattr(self.sampler, "set_epoch"):
             self.sampler.set_epoch(epoch)
 
+    def state_dict(self) -> dict:
+        """This rank's augmentation stream (ints as strings: PCG64's words are 128 bits wide), the sampler epoch and
+        the step count — what ``utils.checkpoint.save_checkpoint(rank_state=...)`` stores per rank."""
+        bg = self.rng.bit_generator.state
+        return {"kind": "gpu", "bit_generator": str(bg["bit_generator"]), "state": str(bg["state"]["state"]),
+                "inc": str(bg["state"]["inc"]), "has_uint32": int(bg["has_uint32"]), "uinteger": int(bg["uinteger"]),
+                "epoch": int(self.epoch), "steps": int(self.steps)}
+
+    def load_state_dict(self, st: dict) -> None:
+        if not st or st.get("kind") != "gpu":
+            return
+        if st["bit_generator"] != self.rng.bit_generator.state["bit_generator"]:
+            raise ValueError(f"loader state was written by a {st['bit_generator']} generator")
+        self.rng.bit_generator.state = {"bit_generator": st["bit_generator"],
+                                        "state": {"state": int(st["state"]), "inc": int(st["inc"])},
+                                        "has_uint32": int(st["has_uint32"]), "uinteger": int(st["uinteger"])}
+        self.steps = int(st.get("steps", 0))
+        self.set_epoch(int(st.get("epoch", 0)))
+
+    def reseed(self, seed: int, rank: int, salt: int) -> None:
+        """A fresh rank-dependent stream (a restore after a non-finite loss must not replay the same batches)."""
+        self.rng = np.random.default_rng([seed, rank, 0x9E37, salt])
+
     def prepare(self, progress=None) -> None:
         if self.mode == "cache" and self.store is None:
             self.store = DeviceSampleStore(len(self.raw), self.slot, self.device, self.label_fill)

@@ -159,6 +159,7 @@ class AlignedXception(nn.Module):
 
     def __init__(self, output_stride: int = 16, in_channels: int = 3, pad_mid: Optional[bool] = None):
         super().__init__()
+        rng_at_entry = torch.get_rng_state()
         if output_stride == 16:
             entry3_stride, mid_dil, exit_dil = 2, 1, (1, 2)
         elif output_stride == 8:
@@ -195,9 +196,17 @@ class AlignedXception(nn.Module):
         for blk in chain:
             blk.input_sole = blk is not self.block2
         if mid != MID_CHANNELS:
-            self.zero_pad_channels()
             self._register_state_dict_hook(_logical_state_dict)
             self._register_load_state_dict_pre_hook(self._physical_state_dict)
+            # Initialise as the 728-channel network does: the 768-wide layers drew kaiming_normal_ with their physical
+            # fan-out (2.6 % smaller std) and consumed another stretch of the generator.  Re-draw at the logical
+            # shapes from the generator state this constructor was entered with — same seed, same weights as the
+            # unpadded (stock / CPU) model, and the generator is left where that model's constructor leaves it.
+            torch.set_rng_state(rng_at_entry)
+            twin = AlignedXception(output_stride, in_channels, pad_mid=False)
+            self.load_state_dict(twin.state_dict())
+            del twin
+            self.zero_pad_channels()
 
     # ---- physical 768-wide storage of the 728-channel flow (module docstring) ----
     def _padded_tensors(self):
@@ -244,6 +253,25 @@ class AlignedXception(nn.Module):
                         else torch.zeros(shape, dtype=t.dtype, device=t.device)
                     t = torch.cat([t, fill], dim=d)
             state_dict[key] = t
+
+    # ---- per-parameter state kept OUTSIDE the state_dict (optimizer momentum: parallel.optim.FlatSGD) ----
+    def state_to_logical(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        """A tensor shaped like parameter ``key`` (relative to this module) in the architecture's 728-wide shape."""
+        if self.mid_physical != MID_CHANNELS and key.startswith(_PADDED):
+            for d in range(min(t.dim(), 2)):
+                if t.shape[d] == self.mid_physical:
+                    t = t.narrow(d, 0, MID_CHANNELS)
+        return t
+
+    def state_to_physical(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        """The inverse for additive state (momentum): the padding channels' share is zero."""
+        if self.mid_physical != MID_CHANNELS and key.startswith(_PADDED):
+            for d in range(min(t.dim(), 2)):
+                if t.shape[d] == MID_CHANNELS:
+                    shape = list(t.shape)
+                    shape[d] = self.mid_physical - MID_CHANNELS
+                    t = torch.cat([t, torch.zeros(shape, dtype=t.dtype, device=t.device)], dim=d)
+        return t
 
     def forward(self, x):
         x = conv_bn_act(self.conv1, self.bn1, x, relu=True)

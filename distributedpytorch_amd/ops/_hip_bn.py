@@ -32,7 +32,7 @@ def _lib():
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         lib.dp_bn_fold.argtypes = [c_void_p, c_int, c_long] + [c_void_p] * 4 + [c_float] * 3 + [c_void_p] * 7 + \
             [c_float, c_int, c_int, c_void_p]
-        lib.dp_bn_fold_bwd.argtypes = [c_void_p] * 11 + [c_float, c_float, c_int, c_int, c_void_p]
+        lib.dp_bn_fold_bwd.argtypes = [c_void_p] * 11 + [c_float, c_float, c_int, c_int, c_int, c_void_p]
         lib.dp_bn3fold_rows.argtypes = [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]
         lib.dp_bn3fold_coef.argtypes = [c_void_p] * 6 + [c_float, c_float] + [c_void_p] * 5 + [c_int, c_int, c_void_p]
         lib.dp_bn3fold_comb.argtypes = [c_void_p] * 11 + [c_int, c_int, c_void_p]
@@ -265,10 +265,13 @@ def fold_into_pointwise(stats, weight, bias, running_mean, running_var, count, e
     return wf, vec, bprime
 
 
-def fold_backward(dwf, w_lowp, vec, weight, dw_sink, dgamma_sink, count, sink_scale=1.0):
+def fold_backward(dwf, w_lowp, vec, weight, dw_sink, dgamma_sink, count, sink_scale=1.0, reduce_ds=None):
     """Backward of ``fold_into_pointwise``: ``dwf`` fp32 [Cout, Cin, 1, 1] (KRSC) is the gradient w.r.t. the
     FOLDED weights.  Adds dW = dwf * scale into ``dw_sink`` and d(gamma) into ``dgamma_sink``; returns
-    cc fp32 [2, Cin] = (c, -c * mean) with dz = W'^T dy + c * z + (-c * mean)."""
+    cc fp32 [2, Cin] = (c, -c * mean) with dz = W'^T dy + c * z + (-c * mean).
+    ``reduce_ds``: synchronised statistics — called on ds = sum_k dW'_kj W_kj (fp32 [Cin]) between the two kernels
+    to sum it over the ranks; ``count`` is then the global row count and ``sink_scale`` (1 / world) applies to
+    d(gamma) only (the weight gradient is local)."""
     cout, cin = w_lowp.shape[:2]
     for t, nm in ((dwf, "dwf"), (dw_sink, "dw_sink")):
         if t.dtype != torch.float32 or tuple(t.shape) != (cout, cin, 1, 1) or not t.permute(0, 2, 3, 1).is_contiguous():
@@ -278,10 +281,14 @@ def fold_backward(dwf, w_lowp, vec, weight, dw_sink, dgamma_sink, count, sink_sc
     _check_vec(weight, cin, "weight"); _check_vec(dgamma_sink, cin, "dgamma_sink")
     ds = workspace.zeros(cin, w_lowp.device)
     cc = torch.empty(2, cin, dtype=torch.float32, device=w_lowp.device)
-    B.check(_lib().dp_bn_fold_bwd(B.ptr(dwf), B.ptr(w_lowp), B.ptr(vec[0]), B.ptr(weight), B.ptr(vec[2]),
-                                  B.ptr(vec[1]), B.ptr(dw_sink), B.ptr(ds), B.ptr(cc[0]), B.ptr(cc[1]),
-                                  B.ptr(dgamma_sink), float(count), float(sink_scale), cout, cin, B.stream_ptr()),
-            "bn_fold_bwd")
+    args = (B.ptr(dwf), B.ptr(w_lowp), B.ptr(vec[0]), B.ptr(weight), B.ptr(vec[2]), B.ptr(vec[1]), B.ptr(dw_sink),
+            B.ptr(ds), B.ptr(cc[0]), B.ptr(cc[1]), B.ptr(dgamma_sink), float(count), float(sink_scale), cout, cin)
+    if reduce_ds is None:
+        B.check(_lib().dp_bn_fold_bwd(*args, 0, B.stream_ptr()), "bn_fold_bwd")
+    else:
+        B.check(_lib().dp_bn_fold_bwd(*args, 1, B.stream_ptr()), "bn_fold_bwd")
+        reduce_ds(ds)
+        B.check(_lib().dp_bn_fold_bwd(*args, 2, B.stream_ptr()), "bn_fold_bwd")
     return cc
 
 

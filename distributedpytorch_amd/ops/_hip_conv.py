@@ -125,7 +125,7 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
         if cfg is None and B.deterministic():
             cfg = 1                    # no timing-dependent choice: the table's tile or the default
         elif cfg is None:
-            cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device) if _AUTOTUNE else 1
+            cfg = _TUNED[key] = _agreed(lambda: _autotune(args, stats, reps, cout, x.device)) if _AUTOTUNE else 1
             _save_tuned()
     if residual is not None:
         if (residual.dtype != torch.bfloat16 or residual.shape != y.shape or stats is not None
@@ -170,7 +170,24 @@ _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
 # same box).  17 / 18 (their 8-wave forms) were never picked in three tuning runs: selectable, not tried.
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 14, 15, 16, 0)
 _TUNED: dict = {}
-_TUNE_COUNTS = {"packaged": 0, "measured_here": 0}
+_TUNE_COUNTS = {"packaged": 0, "measured_here": 0, "timed_on_this_rank": 0}
+
+
+def _agreed(measure) -> int:
+    """The choice for a problem that is in no table.  One process: ``measure()``.  Several ranks: rank 0 measures
+    and everybody runs ITS choice (one small broadcast per new problem; every rank meets the same problems in the
+    same order: same model, same per-rank batch) — per-rank timing noise flips near-ties (20 of 101 problems
+    between two runs of one box), and under data parallelism the slowest rank's pick gates every step."""
+    from ..parallel import dist_env
+    _TUNE_COUNTS["measured_here"] += 1
+    if dist_env.get_world_size() <= 1:
+        _TUNE_COUNTS["timed_on_this_rank"] += 1
+        return int(measure())
+    val = 0
+    if dist_env.is_master():
+        _TUNE_COUNTS["timed_on_this_rank"] += 1
+        val = int(measure())
+    return dist_env.broadcast_int(val, 0)
 
 
 def _load_tuned(path: str) -> None:
@@ -206,13 +223,13 @@ def _save_tuned() -> None:
 
 def tune_report() -> dict:
     """How the tile configurations of this process were decided: ``packaged`` = entries of the shipped table
-    (ops/tuned_gfx950.json) at import, ``measured_here`` = problems autotuned in this process (0 means every
-    problem hit the table: all ranks run identical tiles from the first step)."""
+    (ops/tuned_gfx950.json) at import, ``measured_here`` = problems decided in this run (0 means every problem hit
+    the table), ``timed_on_this_rank`` = how many of those this rank timed itself (all of them in one process,
+    all on rank 0 / none elsewhere under data parallelism: ``_agreed``)."""
     return dict(_TUNE_COUNTS, entries=len(_TUNED), autotune=_AUTOTUNE, forced_cfg=_FORCED_CFG)
 
 
 def _autotune(args, stats, reps, cout, device, runner=None, candidates=None) -> int:
-    _TUNE_COUNTS["measured_here"] += 1
     lib = _lib()
     stream = B.stream_ptr()
     a = list(args)
@@ -315,9 +332,11 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
         cfg = 1
     elif cfg is None:
         if _AUTOTUNE:
-            scratch = torch.zeros(reps * 2 * cout, dtype=torch.float32, device=dy.device)
-            cfg = _autotune((), None, 1, cout, dy.device,
-                            runner=lambda a, c, stream: -2 if c == 0 else launch(c, B.ptr(scratch), stream))
+            def measure():
+                scratch = torch.zeros(reps * 2 * cout, dtype=torch.float32, device=dy.device)
+                return _autotune((), None, 1, cout, dy.device,
+                                 runner=lambda a, c, stream: -2 if c == 0 else launch(c, B.ptr(scratch), stream))
+            cfg = _agreed(measure)
         else:
             cfg = 1
         _TUNED[key] = cfg
@@ -424,7 +443,8 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
         key = ("wgrad", n, hi, wi, cin, ho, wo, cout, r, s, tuple(stride), tuple(pad), tuple(dil))
         splits = _TUNED.get(key)
         if splits is None:
-            splits = _TUNED[key] = _autotune_wgrad(dy, x, dw, (n, hi, wi, cin, ho, wo, cout, r, s), stride, pad, dil)
+            splits = _TUNED[key] = _agreed(
+                lambda: _autotune_wgrad(dy, x, dw, (n, hi, wi, cin, ho, wo, cout, r, s), stride, pad, dil))
             _save_tuned()
     B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
                                  stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, _WGRAD_GEN1,
@@ -440,7 +460,6 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil, runner=None) -> int:
     blocks, 81 us at 576), so the cost model's choice (0) competes with counts that land on
     0.5 / 0.75 / 1 / 1.5 / 2 / 3 rounds of blocks."""
     n, hi, wi, cin, ho, wo, cout, r, s = geom
-    _TUNE_COUNTS["measured_here"] += 1
     lib, stream = _lib(), B.stream_ptr()
     # blocks own 256 output channels when Cout fills them (csrc/conv_wgrad.hip, G = 2), else 128
     pad256, pad128 = (cout + 255) // 256 * 256, (cout + 127) // 128 * 128
@@ -656,8 +675,8 @@ class _StemConv(torch.autograd.Function):
         elif cfg is None:
             def runner(a, c, stream):
                 return -2 if c == 0 else _lib().dp_conv_igemm2w(*a, c, 4, stream)
-            cfg = _TUNED[key] = _autotune(args, stats, reps, cout, x.device, runner,
-                                          (7, 13, 6, 1, 3, 12)) if _AUTOTUNE else 7
+            cfg = _TUNED[key] = _agreed(lambda: _autotune(args, stats, reps, cout, x.device, runner,
+                                                          (7, 13, 6, 1, 3, 12))) if _AUTOTUNE else 7
             _save_tuned()
         B.check(_lib().dp_conv_igemm2w(*args, cfg, 4, B.stream_ptr()), "conv_igemm2w")
         ctx.save_for_backward(xp)
@@ -697,8 +716,9 @@ class _StemConv(torch.autograd.Function):
             key = ("stem_wgrad", n, hi, wp_px, ho, wo, cout, r, stride[0], padding[0])
             splits = _TUNED.get(key)
             if splits is None:
-                splits = _TUNED[key] = _autotune_wgrad(dy, xp, dwp, (n, hi, wp_px, _STEM_WINDOW, ho, wo, cout, r, 1),
-                                                       stride, padding, (1, 1), run)
+                splits = _TUNED[key] = _agreed(
+                    lambda: _autotune_wgrad(dy, xp, dwp, (n, hi, wp_px, _STEM_WINDOW, ho, wo, cout, r, 1),
+                                            stride, padding, (1, 1), run))
                 _save_tuned()
         B.check(run(B.ptr(dwp), splits, B.stream_ptr()), "conv_wgrad_win")
         dw = dwp.view(cout, r, _STEM_WINDOW // 4, 4)[:, :, :s, :cin].permute(0, 3, 1, 2)    # [Cout, Cin, R, S]

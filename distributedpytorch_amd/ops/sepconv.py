@@ -15,6 +15,9 @@ scales the weights, the MFMA implicit-GEMM consumes the raw ``z``.  Per unit and
 read+write pass over the (728-channel, stride-8) activation in forward and two in backward (the measured profile
 of the unfused path: profiles/r2_x65_os8_b64_v28_profile.md, BatchNorm kernels 121 of 307 ms).
 
+Synchronised statistics (``bn1.sync``): the partial sums of z are all-reduced before the fold (forward) and ds
+before the coefficient c is formed (backward); dW stays a local gradient.
+
 Backward, with dW' the weight gradient w.r.t. the folded weights (computed by the ordinary weight-gradient kernel
 on the raw z) and M = N*H*W:
 
@@ -53,11 +56,20 @@ class _FoldedPointwise(torch.autograd.Function):
     """y', stats(y') = (W diag(s)) z with s from the statistics of z.  Inputs 1-3 are differentiable."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, weight, stats1, w_lowp, bn1, bn2):
+    def forward(ctx, z, gamma, beta, weight, stats1, w_lowp, bn1, bn2, group=False):
         from . import _hip_bn, _hip_conv
+        from .batchnorm import _group_active, _small_all_reduce
         n, cin, h, w = z.shape
         cout = weight.shape[0]
         count = float(n * h * w)
+        # synchronised statistics (bn1.sync): the partial sums of z are all-reduced in place — one message — and the
+        # fold runs on the global mean / variance; backward sums ds over the ranks the same way
+        ctx.sync = _group_active(group)
+        ctx.pg = None if group is True else group
+        if ctx.sync:
+            import torch.distributed as dist
+            _small_all_reduce(stats1.view(-1), ctx.pg)
+            count *= dist.get_world_size(ctx.pg)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         wf, vec, _ = _hip_bn.fold_into_pointwise(stats1, g32, b32, bn1.running_mean, bn1.running_var, count, bn1.eps,
                                                  bn1.momentum, w_lowp, bn2.running_mean, bn2.momentum)
@@ -75,8 +87,9 @@ class _FoldedPointwise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _unused=None):
         if dy is None:
-            return (None,) * 8
+            return (None,) * 9
         from . import _hip_bn, _hip_conv, streams
+        from .batchnorm import _small_all_reduce
         z, wf, w_lowp, vec, g32 = ctx.saved_tensors
         gamma, beta, weight = ctx.params
         cout, cin = wf.shape[:2]
@@ -111,8 +124,13 @@ class _FoldedPointwise(torch.autograd.Function):
             dw = torch.zeros_like(dwf)
         if g_sink is None:
             dgamma = torch.zeros(cin, dtype=torch.float32, device=z.device)
+        sink_scale, reduce_ds = 1.0, None
+        if ctx.sync:
+            import torch.distributed as dist
+            sink_scale = 1.0 / dist.get_world_size(ctx.pg)
+            reduce_ds = (lambda t: _small_all_reduce(t, ctx.pg))
         cc = _hip_bn.fold_backward(dwf, w_lowp, vec, g32, w_sink if w_sink is not None else dw,
-                                   g_sink if g_sink is not None else dgamma, ctx.count)
+                                   g_sink if g_sink is not None else dgamma, ctx.count, sink_scale, reduce_ds)
         if need_dz and serial:
             # 2. dz = W'^T dy + c * z - c * mean in ONE kernel: the statistics term rides in the store loop
             dz = _hip_conv.igemm(dy, _hip_conv.weight_transpose(wf), (h, w), 1, 1, (0, 0), (1, 1),
@@ -130,14 +148,14 @@ class _FoldedPointwise(torch.autograd.Function):
                 notify = getattr(prm, "_dpamd_on_grad", None)
                 if notify is not None and prm.requires_grad:
                     notify(prm)
-        return dz, dgamma, dbeta, dw, None, None, None, None
+        return dz, dgamma, dbeta, dw, None, None, None, None, None
 
 
 def can_fold(sep, bn2, x: torch.Tensor) -> bool:
     dw, bn1, pw = sep.conv1, sep.bn, sep.pointwise
     return (_FOLD and B.use_hip(x) and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
-            and bn1.training and not bn1.frozen and not bn1.sync
-            and bn2.training and not bn2.frozen and not bn2.sync and 0.0 <= bn2.momentum < 1.0
+            and bn1.training and not bn1.frozen
+            and bn2.training and not bn2.frozen and 0.0 <= bn2.momentum < 1.0
             and dw.can_fuse_stats(x) and pw.bias is None and pw.groups == 1 and pw.kernel_size == (1, 1)
             and pw.stride == (1, 1) and pw.padding == (0, 0)
             and pw.in_channels % 8 == 0 and pw.out_channels % 8 == 0 and pw.in_channels <= 8192)
@@ -172,6 +190,10 @@ def sepconv_bn_act(sep, bn2, x: torch.Tensor, relu: bool = False, residual: Opti
     else:
         z, stats1 = dw(x, with_stats=True, sole_consumer=sole_consumer)
     bn1, pw = sep.bn, sep.pointwise
-    y, stats2 = _FoldedPointwise.apply(z, bn1.weight, bn1.bias, pw.weight, stats1, pw.lowp_weight(x.dtype), bn1, bn2)
+    group = False
+    if bn1.sync:
+        group = bn1.process_group if bn1.process_group is not None else True
+    y, stats2 = _FoldedPointwise.apply(z, bn1.weight, bn1.bias, pw.weight, stats1, pw.lowp_weight(x.dtype), bn1, bn2,
+                                       group)
     out = bn2(y, relu=relu, residual=residual, stats=stats2, dropout=dropout)
     return (out, skip if pt else x) if passthrough else out

@@ -98,6 +98,10 @@ class DistributedDataParallel(nn.Module):
         self._comm = self.world_size > 1 or (_FORCE and dist.is_initialized())
         self._rank = dist.get_rank(process_group) if (dist.is_available() and dist.is_initialized()) else 0
         self._cs_dirty = False
+        # per-bucket timeline of ONE step (profile_next_step / comm_profile): events on the comm-launch stream
+        self._prof_armed = False
+        self._prof: Optional[dict] = None
+        self._prof_result: Optional[dict] = None
         if self._comm:
             self._broadcast_initial_state(broadcast_buffers)
         self._install_hooks()
@@ -166,6 +170,29 @@ class DistributedDataParallel(nn.Module):
             self._comm_stream = torch.cuda.Stream(device=device)      # only event waits (+ staged copies under gloo) run here
         return self._comm_stream
 
+    # ------------------------------------------------------------------ per-bucket timeline
+    def profile_next_step(self) -> None:
+        """Record, for the NEXT step, when each bucket's collective could start (all its gradients written) and when
+        it finished, on the GPU's clock relative to the start of forward, plus the end of backward: which bucket is
+        exposed, and by how much, is then one subtraction (bench.py ``comm.buckets``).  Costs two events per bucket
+        and makes the comm-launch stream wait for each collective (they are serialised on RCCL's stream anyway)."""
+        self._prof_armed = bool(self._comm and self.arena.flat_g.is_cuda)
+
+    def comm_profile(self) -> Optional[dict]:
+        """The timeline recorded by the last profiled step (after a device synchronisation), or None."""
+        p = self._prof_result
+        if p is None:
+            return None
+        torch.cuda.synchronize(self.arena.flat_g.device)
+        t0 = p["t0"]
+        out = {"backward_end_ms": round(t0.elapsed_time(p["bwd_end"]), 3), "buckets": []}
+        for b, nbytes, e_ready, e_done in p["buckets"]:
+            out["buckets"].append({"bucket": b, "bytes": nbytes, "launch_ms": round(t0.elapsed_time(e_ready), 3),
+                                   "done_ms": round(t0.elapsed_time(e_done), 3)})
+        last_done = max((x["done_ms"] for x in out["buckets"]), default=0.0)
+        out["exposed_after_backward_ms"] = round(max(0.0, last_done - out["backward_end_ms"]), 3)
+        return out
+
     def _collective(self, g: torch.Tensor) -> None:
         from .dist_env import all_reduce_, _stage_through_host
         pg = self.process_group
@@ -198,7 +225,17 @@ class DistributedDataParallel(nn.Module):
             cs.wait_stream(torch.cuda.current_stream(g.device))
             streams.join_into(cs, g.device)
             with torch.cuda.stream(cs):
-                self._collective(g)
+                if self._prof is not None:
+                    e_ready, e_done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e_ready.record(cs)
+                    n0 = len(self._works)
+                    self._collective(g)
+                    for w in self._works[n0:]:
+                        w.wait()                       # (cs, not the step's stream, waits for the collective)
+                    e_done.record(cs)
+                    self._prof["buckets"].append((b, g.numel() * 4, e_ready, e_done))
+                else:
+                    self._collective(g)
             self._cs_dirty = True
         else:
             if g.is_cuda:
@@ -219,6 +256,9 @@ class DistributedDataParallel(nn.Module):
     def finish_gradient_sync(self) -> float:
         """Launch whatever did not fire (unused parameters), wait for every bucket, and return the
         scale that turns the summed gradients into the average."""
+        if self._prof is not None:
+            self._prof["bwd_end"] = torch.cuda.Event(enable_timing=True)
+            self._prof["bwd_end"].record()
         if self._sync_enabled:
             for b in range(self._next, len(self.arena.buckets)):
                 self._launch(b)
@@ -235,6 +275,8 @@ class DistributedDataParallel(nn.Module):
         if debug.ENABLED and self._sync_enabled and self._comm:
             debug.check_bucket_order(self._order, debug._comm_device(self.arena.flat_g))
             debug.check_gradients_equal(self.arena.flat_g, self.arena)
+        if self._prof is not None:
+            self._prof_result, self._prof = self._prof, None
         self.reset_buckets()
         return 1.0 / self.world_size
 
@@ -255,4 +297,8 @@ class DistributedDataParallel(nn.Module):
         return DistributedDataParallel._NoSync(self)
 
     def forward(self, *args, **kwargs):
+        if self._prof_armed:
+            self._prof_armed = False
+            self._prof = {"t0": torch.cuda.Event(enable_timing=True), "buckets": []}
+            self._prof["t0"].record()
         return self.module(*args, **kwargs)

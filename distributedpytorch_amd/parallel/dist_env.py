@@ -150,6 +150,16 @@ def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
     dist.broadcast(t, src=src, group=group)
 
 
+def broadcast_int(value: int, src: int = 0) -> int:
+    """``value`` of rank ``src`` on every rank (a one-element message; the caller is off the hot path: tile
+    choices of a new problem, ops._hip_conv)."""
+    if get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_default_device())
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def all_reduce_scalar(value: float, op: str = "sum", device: Optional[torch.device] = None) -> float:
     if get_world_size() == 1:
         return float(value)

@@ -57,7 +57,9 @@ class TrainEngine:
         self.criterion = criterion
         if getattr(criterion, "fuses_upsample", False) and hasattr(model, "defer_upsample"):
             model.defer_upsample = True
-        self.optimizer = FlatSGD(self.ddp.arena, [lr * m for m in mults], momentum, weight_decay)
+        adapters = [(name + "." if name else "", m) for name, m in model.named_modules()
+                    if hasattr(m, "state_to_logical") and hasattr(m, "state_to_physical")]
+        self.optimizer = FlatSGD(self.ddp.arena, [lr * m for m in mults], momentum, weight_decay, adapters=adapters)
         self.accum_steps = max(int(accum_steps), 1)
         self._micro = 0
         self.timer = PhaseTimer(self.on_gpu, markers)

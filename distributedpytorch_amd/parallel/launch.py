@@ -4,8 +4,9 @@ The reference drives its 4 GPUs from a single ``python train_pascal.py`` (one pr
 ``nn.DataParallel``, `/root/reference/train_pascal.py:92`); its TODO header (`:7-8`) names the missing
 pieces of the per-process design — device from the local rank, an explicit rendezvous port.  Here the
 same one command works: ``python bench.py --gpus 8`` / ``python train_pascal.py --gpus 8``.  The
-PARENT never touches the GPU (no HIP call, no ``torch.cuda.is_available()``; only
-``torch.cuda.device_count()``, which does not create a context): it picks a free rendezvous port,
+PARENT never touches the GPU: it counts the devices from the KFD topology in sysfs (no HIP call at all —
+``torch.cuda.device_count()`` falls through to ``hipGetDeviceCount`` when ``amdsmi`` is absent, which starts
+the HIP runtime — so that is only the fall-back when sysfs has no topology), picks a free rendezvous port,
 starts N fresh children with the torchrun environment contract (``RANK``, ``LOCAL_RANK``,
 ``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT``), waits for them, and exits with the first non-zero
 status after stopping the survivors — a dead rank must not leave the others blocked in a collective.
@@ -39,11 +40,59 @@ def already_a_rank() -> bool:
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _mask_count(total: int) -> int:
+    """Apply the visibility masks a child would see (comma lists of indices; UUID entries count as one each)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is None:
+            continue
+        items = [t for t in v.split(",") if t.strip() != ""]
+        n = 0
+        for t in items:
+            t = t.strip()
+            if t.lstrip("-").isdigit() and not 0 <= int(t) < total:
+                break                                    # the runtime stops at the first invalid index
+            n += 1
+        total = min(total, n)
+    return total
+
+
+def kfd_gpu_count(root: str = KFD_NODES) -> Optional[int]:
+    """GPU nodes of the KFD topology: a node is a GPU when its ``properties`` file has ``simd_count`` > 0 (CPU
+    nodes carry 0).  None when the topology cannot be read (no amdgpu driver, restricted container)."""
+    try:
+        nodes = sorted(os.listdir(root))
+    except OSError:
+        return None
+    n, readable = 0, False
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        readable = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n if readable else None
+
+
 def visible_gpus() -> int:
-    """Number of devices, without creating a GPU context in this process."""
+    """Number of devices a child will see, without starting the HIP runtime in this process when sysfs can tell."""
+    n = kfd_gpu_count()
+    if n is not None:
+        # a container may show the host's whole topology but pass only some render nodes through
+        import glob
+        nodes = glob.glob("/dev/dri/renderD*")
+        if nodes:
+            n = min(n, sum(os.access(d, os.R_OK | os.W_OK) for d in nodes))
+        return _mask_count(n)
     try:
         import torch
-        return int(torch.cuda.device_count())
+        return int(torch.cuda.device_count())            # starts the runtime; the parent never execs, so harmless
     except Exception:
         return 0
 

@@ -7,17 +7,22 @@ subsumes ``optimizer.step(); optimizer.zero_grad()`` (`train_pascal.py:222-224`)
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
 from ..ops.sgd import sgd_flat_step_
-from .arena import ParamArena
+from .arena import ParamArena, _view_like
 
 
 class FlatSGD:
     def __init__(self, arena: ParamArena, lr: float | Sequence[float], momentum: float = 0.9,
-                 weight_decay: float = 5e-4):
+                 weight_decay: float = 5e-4, adapters: Optional[Sequence[Tuple[str, object]]] = None):
+        """``adapters``: ``(prefix, module)`` pairs whose ``state_to_logical(key, t)`` / ``state_to_physical(key, t)``
+        translate per-parameter state of parameters named ``prefix + key`` between the stored layout and the
+        architecture's (models.xception: the 728-channel flow stored 768 wide).  The sidecar then holds LOGICAL
+        shapes, so a checkpoint written by a padded run resumes into an unpadded model and back."""
+        self.adapters = list(adapters or [])
         ngroups = max(s.group for s in arena.slots) + 1
         lrs = [lr] * ngroups if isinstance(lr, (int, float)) else list(lr)
         assert len(lrs) == ngroups
@@ -54,16 +59,49 @@ class FlatSGD:
         self.arena.zero_grad()
 
     # ---- sidecar state (optimiser state lives beside, not inside, the weights) ----
+    def _adapt(self, name: str, t: torch.Tensor, to_logical: bool) -> torch.Tensor:
+        for prefix, mod in self.adapters:
+            if name.startswith(prefix):
+                fn = mod.state_to_logical if to_logical else mod.state_to_physical
+                return fn(name[len(prefix):], t)
+        return t
+
     def state_dict(self) -> Dict:
-        return {"momentum": self.arena.flat_m.detach().cpu(), "steps": self._steps,
-                "names": [s.name for s in self.arena.slots],
-                "offsets": [s.offset for s in self.arena.slots],
+        """Momentum PER PARAMETER in the architecture's shapes (not the arena's flat, possibly padded layout)."""
+        m = self.arena.flat_m.detach()
+        by_name = {}
+        for s in self.arena.slots:
+            t = _view_like(m, s.offset, s.param)              # logical shape (4-D weights lie KRSC in the arena)
+            by_name[s.name] = self._adapt(s.name, t, True).cpu().contiguous().clone()
+        return {"format": 2, "momentum_by_name": by_name, "steps": self._steps,
                 "lrs": [pg["lr"] for pg in self.param_groups]}
 
     def load_state_dict(self, sd: Dict) -> None:
-        if sd["names"] != [s.name for s in self.arena.slots]:
-            raise ValueError("optimizer sidecar does not match this model's parameter arena")
-        self.arena.flat_m.copy_(sd["momentum"].to(self.arena.flat_m.device))
+        slots = self.arena.slots
+        if "momentum_by_name" in sd:
+            by_name = sd["momentum_by_name"]
+            missing = [s.name for s in slots if s.name not in by_name]
+            extra = sorted(set(by_name) - {s.name for s in slots})
+            if missing or extra:
+                raise ValueError(f"optimizer sidecar does not match this model: missing {missing[:3]}, "
+                                 f"unexpected {extra[:3]}")
+            dev = self.arena.flat_m.device
+            for s in slots:
+                t = self._adapt(s.name, by_name[s.name].to(dev), False)
+                if tuple(t.shape) != tuple(s.param.shape):
+                    raise ValueError(f"optimizer sidecar: momentum of '{s.name}' has shape {tuple(by_name[s.name].shape)}, "
+                                     f"the parameter is {tuple(s.param.shape)}")
+                _view_like(self.arena.flat_m, s.offset, s.param).copy_(t)
+        else:
+            # round-1/2 sidecars: one flat buffer in the WRITER's arena layout — only a reader with the identical
+            # layout may take it (a padded Xception arena against an unpadded one would scramble the momentum)
+            if sd.get("names") != [s.name for s in slots]:
+                raise ValueError("optimizer sidecar does not match this model's parameter arena")
+            if sd.get("offsets") != [s.offset for s in slots] or sd["momentum"].numel() != self.arena.flat_m.numel():
+                raise ValueError("optimizer sidecar was written with another arena layout (e.g. the 768-wide stored "
+                                 "Xception flow, DPAMD_X65_PAD); re-save it with this version or resume with the "
+                                 "writer's padding setting")
+            self.arena.flat_m.copy_(sd["momentum"].to(self.arena.flat_m.device))
         self._steps = int(sd["steps"])
         for pg, lr in zip(self.param_groups, sd["lrs"]):
             pg["lr"] = lr

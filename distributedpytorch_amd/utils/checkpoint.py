@@ -48,18 +48,32 @@ def _atomic_save(obj: Any, path: str) -> None:
     os.replace(tmp, path)
 
 
+def rank_state_path(path: str, rank: Optional[int] = None) -> str:
+    return f"{path}.state.rank{dist_env.get_rank() if rank is None else rank}"
+
+
 def save_checkpoint(path: str, model: nn.Module, optimizer=None, extra: Optional[Dict] = None,
-                    sync: bool = True) -> None:
-    """Weights → ``path`` (reference-loadable); optimiser/epoch/RNG → ``path + '.state'``."""
+                    sync: bool = True, rank_state: Optional[Dict] = None) -> None:
+    """Weights → ``path`` (reference-loadable); optimiser/epoch/rank 0's RNG → ``path + '.state'`` (rank 0);
+    EVERY rank's own random state → ``path + '.state.rank<r>'``: its torch / NumPy / dropout-counter state plus
+    ``rank_state`` (whatever else decides that rank's data stream: the device batch loader's generator, the
+    sampler epoch).  A resumed rank takes ITS file back — installing rank 0's state everywhere would give all
+    ranks one augmentation stream."""
     if sync:
         dist_env.barrier()
     if dist_env.is_master():
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         _atomic_save(reference_state_dict(model), path)
-        side: Dict[str, Any] = {"extra": dict(extra or {}), **capture_rng_state()}
+        side: Dict[str, Any] = {"extra": dict(extra or {}), "world_size": dist_env.get_world_size(),
+                                **capture_rng_state()}
         if optimizer is not None:
             side["optimizer"] = optimizer.state_dict()
         _atomic_save(side, path + ".state")
+    if sync:
+        dist_env.barrier()            # the directory exists before the other ranks write beside it
+    if dist_env.get_world_size() > 1 or rank_state is not None:
+        _atomic_save({"rank": dist_env.get_rank(), "world_size": dist_env.get_world_size(),
+                      "rank_state": dict(rank_state or {}), **capture_rng_state()}, rank_state_path(path))
     if sync:
         dist_env.barrier()
 
@@ -79,15 +93,32 @@ def load_weights(path: str, model: nn.Module, strict: bool = True, map_location=
 
 
 def load_checkpoint(path: str, model: nn.Module, optimizer=None, strict: bool = True) -> Dict:
+    """Returns the sidecar's ``extra`` dict; ``extra['rank_state']`` is this rank's own ``rank_state`` of the save
+    (or ``{}``).  Random state: this rank's file when there is one written by a job of the same size; otherwise
+    rank 0 takes the sidecar's and the other ranks KEEP the streams they derived from seed and rank."""
     load_weights(path, model, strict)
     extra: Dict = {}
     side_path = path + ".state"
+    world, rank = dist_env.get_world_size(), dist_env.get_rank()
+    side = None
     if os.path.isfile(side_path):
         side = torch.load(side_path, map_location="cpu", weights_only=True)
-        extra = side.get("extra", {})
+        extra = dict(side.get("extra", {}))
         if optimizer is not None and "optimizer" in side:
             optimizer.load_state_dict(side["optimizer"])
-        restore_rng_state(side)
+    mine = None
+    rp = rank_state_path(path)
+    if os.path.isfile(rp):
+        cand = torch.load(rp, map_location="cpu", weights_only=True)
+        if int(cand.get("world_size", -1)) == world and int(cand.get("rank", -1)) == rank:
+            mine = cand
+    if mine is not None:
+        restore_rng_state(mine)
+        extra["rank_state"] = dict(mine.get("rank_state", {}))
+    else:
+        if side is not None and rank == 0 and int(side.get("world_size", world)) == world:
+            restore_rng_state(side)
+        extra["rank_state"] = {}
     return extra
 
 

@@ -129,3 +129,77 @@ def _engine_worker(rank, world, port, sync_bn):
 @pytest.mark.parametrize("sync_bn", [False, True])
 def test_two_rank_engine_on_gpu_with_debug_checks(sync_bn):
     mp.spawn(_engine_worker, args=(2, _free_port(), sync_bn), nprocs=2, join=True)
+
+
+def _fold_sync_worker(rank, world, port):
+    """The two algebraic folds under synchronised statistics (ops.sepconv: depthwise BN folded into the pointwise
+    weights; ops.bnfold: a bottleneck's last BN folded into conv3's gradients): each rank runs its half of a batch,
+    results must equal the unsynchronised modules on the whole batch."""
+    import copy
+    import faulthandler
+    faulthandler.dump_traceback_later(75, exit=True)      # a stuck rank names its call site and ends the test
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank % torch.cuda.device_count())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.models.resnet import Bottleneck
+    from distributedpytorch_amd.models.xception import XceptionBlock
+    from distributedpytorch_amd.ops import bnfold
+    from distributedpytorch_amd.parallel import p2p
+    from distributedpytorch_amd.parallel.p2p import OneShotAllReduce
+    ar = OneShotAllReduce(None)
+    p2p.ENABLED, p2p._default = True, ar
+    cl = torch.channels_last
+    try:
+        for case in ("xception", "bottleneck"):
+            torch.manual_seed(21)
+            if case == "xception":
+                net = torch.nn.Sequential(XceptionBlock(64, 64, 2, dilation=2), XceptionBlock(64, 64, 2, dilation=1))
+            else:
+                b0, b1 = Bottleneck(64, 16), Bottleneck(64, 16)
+                b0.fold_tail, b1.input_exclusive = True, True
+                net = torch.nn.Sequential(ops.Conv2d(64, 64, 1, bias=False), b0, b1)
+            with torch.no_grad():
+                for m in net.modules():
+                    if hasattr(m, "running_mean"):
+                        m.weight.uniform_(0.6, 1.4); m.bias.normal_(0, 0.5)
+            ref = copy.deepcopy(net).cuda().train()
+            net = ops.convert_sync_batchnorm(net).cuda().train()
+            full = torch.randn(2 * world, 64, 19, 17, device="cuda").to(torch.bfloat16)
+            gfull = torch.randn(2 * world, 64, 19, 17, device="cuda").to(torch.bfloat16)
+            sl = slice(2 * rank, 2 * rank + 2)
+            x = full[sl].contiguous(memory_format=cl).requires_grad_(True)
+            xr = full.contiguous(memory_format=cl).requires_grad_(True)
+            bnfold.COUNTS.update(folded=0, fallback=0)
+            y = net(x)
+            y.backward(gfull[sl].contiguous(memory_format=cl))
+            if case == "bottleneck":
+                assert bnfold.COUNTS["folded"] == 1, bnfold.COUNTS
+            yr = ref(xr)
+            yr.backward(gfull.contiguous(memory_format=cl))
+            torch.cuda.synchronize()
+
+            def cos(a, b):
+                a, b = a.double().flatten(), b.double().flatten()
+                return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+            assert cos(y.float(), yr[sl].float()) > 0.9999, (case, cos(y.float(), yr[sl].float()))
+            assert cos(x.grad.float(), xr.grad[sl].float()) > 0.995, (case, cos(x.grad.float(), xr.grad[sl].float()))
+            for (k, prm), (_, rp) in zip(net.named_parameters(), ref.named_parameters()):
+                gsum = prm.grad.detach().float().clone()
+                dist.all_reduce(gsum)                       # world x DDP's average = the full-batch gradient
+                if float(rp.grad.norm()) > 1e-3:
+                    assert cos(gsum, rp.grad.float()) > 0.995, (case, k, cos(gsum, rp.grad.float()))
+            for (k, b), (_, rb) in zip(net.named_buffers(), ref.named_buffers()):
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    assert torch.allclose(b, rb, atol=2e-2, rtol=2e-2), (case, k)
+        ar.check()
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+        ar.close()
+        p2p._default = None
+        dist.destroy_process_group()
+
+
+def test_folded_paths_under_syncbn_equal_global_batch():
+    mp.spawn(_fold_sync_worker, args=(2, _free_port()), nprocs=2, join=True)

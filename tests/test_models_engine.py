@@ -196,7 +196,7 @@ def test_checkpoint_reference_keyspace_roundtrip(tmp_path):
     m4 = build_model("fcn_resnet18", 21)
     eng4 = TrainEngine(m4, ops.SoftmaxCrossEntropy(255), lr=0.05)
     extra = load_checkpoint(path, eng4.ddp, eng4.optimizer)
-    assert extra == {"epoch": 0, "best_val": 0.5}
+    assert extra == {"epoch": 0, "best_val": 0.5, "rank_state": {}}     # one rank, nothing rank-specific saved
     assert torch.equal(eng4.ddp.arena.flat_m, eng.ddp.arena.flat_m)
     torch.manual_seed(5)            # dropout in the head
     l1 = eng.train_step(x, y)

@@ -30,6 +30,27 @@ def test_self_launch_starts_n_ranks_and_propagates_failure(tmp_path):
     assert launch_ranks(2, [sys.executable, str(bad)]) == 7          # rank 1 dies -> rank 0 is stopped, status kept
 
 
+def test_launcher_counts_gpus_from_the_kfd_topology(tmp_path, monkeypatch):
+    """the parent counted devices with torch.cuda.device_count(), which starts the HIP runtime when
+    amdsmi is absent.  It reads the KFD topology from sysfs instead: nodes with simd_count > 0 are GPUs."""
+    from distributedpytorch_amd.parallel import launch
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\ngfx_target_version 90500\n")
+    assert launch.kfd_gpu_count(str(tmp_path)) == 3
+    assert launch.kfd_gpu_count(str(tmp_path / "nope")) is None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert launch._mask_count(3) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert launch._mask_count(3) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,7,1")                  # the runtime stops at the first bad index
+    assert launch._mask_count(3) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert launch._mask_count(3) == 0
+
+
 def test_bench_self_launch_cpu_reports_two_ranks():
     """`python bench.py --gpus 2` (no torchrun) prints ONE JSON line with n_gpus = 2 — the driver's contract and
     the reference's one-command-many-GPUs behaviour (`/root/reference/train_pascal.py:92`)."""

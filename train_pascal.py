@@ -204,6 +204,13 @@ class StepGuard:
             raise FloatingPointError(f"non-finite loss within the {self.every} steps before step {global_step} "
                                      "on at least one rank")
 
+    def progress(self) -> None:
+        """Re-arm the watchdog without a host read: validation batches, checkpoint writes and figures are progress
+        too — without this an evaluation longer than ``hang_s`` would be taken for a hang."""
+        if self.hang_s > 0:
+            import faulthandler
+            faulthandler.dump_traceback_later(self.hang_s, exit=True)
+
     def close(self) -> None:
         if self.hang_s > 0:
             import faulthandler
@@ -254,11 +261,32 @@ def train_epoch(engine, loader, scheduler, epoch, args, log, guard=None, checker
 class HostLoader:
     """The reference's data path: DataLoader workers run the CPU transforms; dict batches → (inputs, target)."""
 
-    def __init__(self, loader, sampler, kin, kgt):
-        self.loader, self.sampler, self.kin, self.kgt = loader, sampler, kin, kgt
+    def __init__(self, loader, sampler, kin, kgt, generator=None):
+        self.loader, self.sampler, self.kin, self.kgt, self.generator = loader, sampler, kin, kgt, generator
+        self.epoch = 0
 
     def set_epoch(self, epoch):
+        self.epoch = epoch
         self.sampler.set_epoch(epoch)
+
+    def state_dict(self):
+        """The generator the DataLoader draws its workers' base seeds from (this rank's own) and the sampler epoch;
+        NumPy's global state travels with ``utils.checkpoint.capture_rng_state``."""
+        st = {"kind": "host", "epoch": int(self.epoch)}
+        if self.generator is not None:
+            st["generator"] = self.generator.get_state()
+        return st
+
+    def load_state_dict(self, st):
+        if not st or st.get("kind") != "host":
+            return
+        if self.generator is not None and "generator" in st:
+            self.generator.set_state(st["generator"])
+        self.set_epoch(int(st.get("epoch", 0)))
+
+    def reseed(self, seed, rank, salt):
+        if self.generator is not None:
+            self.generator.manual_seed(seed * 1000 + rank + 7919 * salt)
 
     def __len__(self):
         return len(self.loader)
@@ -269,7 +297,7 @@ class HostLoader:
 
 
 @torch.no_grad()
-def validate_instance(engine, loader, args, epoch=0, fig_path=None):
+def validate_instance(engine, loader, args, epoch=0, fig_path=None, tick=None):
     """Per-object Jaccard at thresholds .3/.5/.8 with void pixels excluded (train_pascal.py:280-306); the first
     batch's prediction and attention maps go to a 4-panel PNG (train_pascal.py:257-278)."""
     engine.model.eval()
@@ -280,6 +308,8 @@ def validate_instance(engine, loader, args, epoch=0, fig_path=None):
     for ii, batch in enumerate(loader):
         if args.max_iters and ii >= args.max_iters:
             break
+        if tick is not None:
+            tick()
         x = engine.prepare_input(batch["concat"])
         out = engine.model(x)
         loss_sum += float(engine.criterion(out, batch["crop_gt"].to(engine.device)))
@@ -308,13 +338,15 @@ def validate_instance(engine, loader, args, epoch=0, fig_path=None):
 class _KeyLoader:
     """Adapts dict batches to the (images, target) pairs ``TrainEngine.evaluate`` consumes."""
 
-    def __init__(self, loader, kin, kgt, limit=0):
-        self.loader, self.kin, self.kgt, self.limit = loader, kin, kgt, limit
+    def __init__(self, loader, kin, kgt, limit=0, tick=None):
+        self.loader, self.kin, self.kgt, self.limit, self.tick = loader, kin, kgt, limit, tick
 
     def __iter__(self):
         for i, b in enumerate(self.loader):
             if self.limit and i >= self.limit:
                 return
+            if self.tick is not None:
+                self.tick()                       # StepGuard.progress: a validation batch retired
             yield b[self.kin], b[self.kgt]
 
 
@@ -395,6 +427,7 @@ def main(argv=None):
         load_weights(args.weights, engine.ddp, strict=False)
     best_val = 0.0
     last_ckpt = None
+    resumed_rank_state = {}
     if args.resume_epoch:
         ck = os.path.join(save_dir, "models", model_name + "_epoch-" + str(args.resume_epoch - 1) + ".pth")
         if not os.path.isfile(ck):          # every rank checks the same path: all raise together, none is left waiting
@@ -405,6 +438,7 @@ def main(argv=None):
         # the sidecar carries what the reference keeps in a variable across epochs (train_pascal.py:177, :301-304):
         # without it the first validation after a resume would overwrite <model>_best.pth with a worse model
         best_val = float(extra.get("best_val", 0.0))
+        resumed_rank_state = extra.get("rank_state", {})
         last_ckpt = ck
         if info.is_master:
             print("Resumed: epoch {} best_val {:.4f}".format(extra.get("epoch", args.resume_epoch - 1), best_val))
@@ -434,7 +468,7 @@ def main(argv=None):
         loader = DataLoader(db_train, batch_size=args.trainBatch, sampler=sampler, num_workers=args.workers,
                             drop_last=True, pin_memory=pin, persistent_workers=args.workers > 0, generator=gen,
                             worker_init_fn=_seed_worker(args.seed * 1000 + info.rank))
-        trainloader = HostLoader(loader, sampler, kin, kgt)
+        trainloader = HostLoader(loader, sampler, kin, kgt, gen)
         tf = getattr(db_train, "transform", None) or getattr(getattr(db_train, "dataloaders", [None])[0],
                                                             "transform", None)
         train_tf = [str(t) for t in tf.transforms] if tf is not None else []
@@ -444,6 +478,8 @@ def main(argv=None):
     testloader = DataLoader(db_val, batch_size=test_bs, sampler=val_sampler, num_workers=args.workers,
                             pin_memory=pin)
     scheduler = LR_Scheduler(args.lr_mode, args.lr, args.nEpochs, len(trainloader))
+    # every rank continues ITS OWN augmentation stream (utils.checkpoint writes <ckpt>.state.rank<r> per rank)
+    trainloader.load_state_dict(resumed_rank_state.get("loader", {}))
 
     # parameter report (train_pascal.py:57-70, :156-159, :169)
     p = OrderedDict()
@@ -477,25 +513,37 @@ def main(argv=None):
             if args.on_nonfinite != "restore" or last_ckpt is None or restores >= 3:
                 raise
             restores += 1
-            log.log("restore", epoch=epoch, reason=str(e), checkpoint=last_ckpt, attempt=restores)
             extra = load_checkpoint(last_ckpt, engine.ddp, engine.optimizer)
             engine.ddp.arena.zero_grad()
             best_val = float(extra.get("best_val", best_val))
-            np.random.seed(args.seed * 1000 + info.rank + 7919 * restores)     # do not replay the same batches
+            # the weights are those of the END of epoch extra["epoch"]: training continues with the epoch after it
+            # (LR schedule and sampler permutation included), not with the epoch that failed
+            back_to = int(extra.get("epoch", epoch - 1)) + 1
+            log.log("restore", epoch=epoch, resumed_epoch=back_to, reason=str(e), checkpoint=last_ckpt,
+                    attempt=restores)
+            epoch = min(back_to, epoch)
+            # do not replay the batches that led to the failure: fresh rank-dependent streams for NumPy's global
+            # generator (CPU transforms), the loader's own generator (device path / worker base seeds) and a
+            # re-drawn sampler permutation
+            np.random.seed(args.seed * 1000 + info.rank + 7919 * restores)
+            trainloader.reseed(args.seed, info.rank, restores)
+            sampler.seed = args.seed + 104729 * restores
             continue
         log.log("epoch", epoch=epoch, numImages=len(trainloader) * args.trainBatch * info.world_size,
                 loss=tr_loss, img_per_s=ips, data_wait_ms=wait_ms)
         if (epoch % args.snapshot) == args.snapshot - 1 and epoch != 0:
             last_ckpt = os.path.join(save_dir, "models", model_name + "_epoch-" + str(epoch) + ".pth")
-            save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val})
+            save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val},
+                            rank_state={"loader": trainloader.state_dict()})
+        guard.progress()
         if args.useTest and epoch % args.nTestInterval == (args.nTestInterval - 1):
             fig = os.path.join(save_dir, "figures", "val_epoch-{}.png".format(epoch))
             if instance:
-                res = validate_instance(engine, testloader, args, epoch, fig)
+                res = validate_instance(engine, testloader, args, epoch, fig, tick=guard.progress)
                 score = max(res["jaccard"])
                 log.log("val", epoch=epoch, loss=res["loss"], JACCARD=res["jaccard"])
             else:
-                res = engine.evaluate(_KeyLoader(testloader, kin, kgt, args.max_iters), 21, 255)
+                res = engine.evaluate(_KeyLoader(testloader, kin, kgt, args.max_iters, tick=guard.progress), 21, 255)
                 score = res["miou"]
                 log.log("val", epoch=epoch, loss=res["loss"], mIoU=res["miou"], pixel_acc=res["pixel_acc"])
                 if info.is_master:
@@ -503,14 +551,17 @@ def main(argv=None):
             if score > best_val:
                 best_val = score
                 last_ckpt = os.path.join(save_dir, "models", model_name + "_best.pth")
-                save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val})
+                save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val},
+                            rank_state={"loader": trainloader.state_dict()})
             log.log("time", epoch=epoch, execution_time=timeit.default_timer() - start_time)
+            guard.progress()
         epoch += 1
     guard.close()
     if checker is not None:
         checker.raise_if_flagged()
     save_checkpoint(os.path.join(save_dir, "models", model_name + "_last.pth"), engine.ddp, engine.optimizer,
-                    {"epoch": args.nEpochs - 1, "best_val": best_val})
+                    {"epoch": args.nEpochs - 1, "best_val": best_val},
+                    rank_state={"loader": trainloader.state_dict()})
     log.close()
     dist_env.shutdown()
     return best_val
