@@ -723,7 +723,7 @@ DP_EXPORT long dp_pam_delta_parts(long rows) {
 
 DP_EXPORT int dp_pam_delta(const void* dy, const void* o, float* delta, float* dgamma, long rows, int C,
                            hipStream_t st) {
-    if (rows <= 0 || C <= 0 || C % 512 != 0 || !dy || !o || !delta) return -1;
+    if (rows <= 0 || C <= 0 || C % 8 != 0 || !dy || !o || !delta) return -1;     // (a wave covers 512 channels per pass)
     long blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pam_delta_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_raw*)dy,
@@ -773,5 +773,78 @@ DP_EXPORT int dp_cam_mat(const void* in, int in_kind, void* out, int B, int C, f
     else
         hipLaunchKernelGGL(cam_mat_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)in, (bf16_raw*)out, C,
                            alpha, beta);
+    return DP_LAUNCH_STATUS();
+}
+
+// ---- DANet head tail: the three dropouts in front of the three classifiers, one pass -----------------------------
+// The head ends in conv8(drop(sa + sc)), conv6(drop(sa)), conv7(drop(sc)) with independent masks.  As separate ops
+// that is an add and three dropouts forward (5 reads + 4 writes of a [M, 512] tensor) and three masked scales plus
+// two adds backward; here one kernel reads sa, sc and writes the three dropped tensors (2 reads + 3 writes), one
+// kernel reads the three gradients and writes d_sa, d_sc (3 reads + 2 writes).  Masks are counter-based
+// (common.h: Drop), stream k of a call uses seed_hi + k·0x9E3779B9, and are recomputed in backward.
+namespace {
+
+struct HeadDrop {
+    const bf16_raw* a; const bf16_raw* b; const bf16_raw* c;    // fwd: sa, sc, -      bwd: g(sa), g(sc), g(sum)
+    bf16_raw* o0; bf16_raw* o1; bf16_raw* o2;                   // fwd: drop(sa), drop(sc), drop(sa+sc)   bwd: d_sa, d_sc, -
+    long n8;                                                     // 16-byte chunks
+    Drop drop;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void head_drop_kernel(HeadDrop p) {
+    Drop d0 = p.drop, d1 = p.drop, d2 = p.drop;
+    d1.seed_hi += 0x9E3779B9u; d2.seed_hi += 2u * 0x9E3779B9u;
+    const float sc = p.drop.scale;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < p.n8; q += (long)gridDim.x * blockDim.x) {
+        const unsigned k0 = drop_keep8(q, d0), k1 = drop_keep8(q, d1), k2 = drop_keep8(q, d2);
+        float a[8], b[8], o0[8], o1[8];
+        unpack8(reinterpret_cast<const uint4*>(p.a)[q], a);
+        unpack8(reinterpret_cast<const uint4*>(p.b)[q], b);
+        if (!BWD) {
+            float o2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o0[j] = (k0 >> j) & 1u ? a[j] * sc : 0.f;
+                o1[j] = (k1 >> j) & 1u ? b[j] * sc : 0.f;
+                o2[j] = (k2 >> j) & 1u ? bf2f(f2bf(a[j] + b[j])) * sc : 0.f;      // sa + sc rounds to bf16 first
+            }
+            reinterpret_cast<uint4*>(p.o0)[q] = pack8(o0);
+            reinterpret_cast<uint4*>(p.o1)[q] = pack8(o1);
+            reinterpret_cast<uint4*>(p.o2)[q] = pack8(o2);
+        } else {
+            float c[8];
+            unpack8(reinterpret_cast<const uint4*>(p.c)[q], c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gs = (k2 >> j) & 1u ? c[j] * sc : 0.f;
+                o0[j] = ((k0 >> j) & 1u ? a[j] * sc : 0.f) + gs;
+                o1[j] = ((k1 >> j) & 1u ? b[j] * sc : 0.f) + gs;
+            }
+            reinterpret_cast<uint4*>(p.o0)[q] = pack8(o0);
+            reinterpret_cast<uint4*>(p.o1)[q] = pack8(o1);
+        }
+    }
+}
+
+}  // namespace
+
+// fwd (bwd = 0): a = sa, b = sc, c unused; o0 = drop(sa), o1 = drop(sc), o2 = drop(sa + sc).
+// bwd (bwd = 1): a, b, c = gradients of o0, o1, o2; o0 = d_sa, o1 = d_sc.  n: elements (multiple of 8), all 16-B aligned.
+DP_EXPORT int dp_head_dropout(const void* a, const void* b, const void* c, void* o0, void* o1, void* o2, long n,
+                              unsigned thr, unsigned long long seed, int bwd, hipStream_t st) {
+    if (!a || !b || !o0 || !o1 || n <= 0 || n % 8 || thr == 0 || thr > 65535) return -1;
+    if (bwd ? !c : !o2) return -1;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15) return -3;
+    HeadDrop p{};
+    p.a = (const bf16_raw*)a; p.b = (const bf16_raw*)b; p.c = (const bf16_raw*)c;
+    p.o0 = (bf16_raw*)o0; p.o1 = (bf16_raw*)o1; p.o2 = (bf16_raw*)o2;
+    p.n8 = n / 8;
+    p.drop.thr = thr; p.drop.scale = 65536.f / (float)(65536u - thr);
+    p.drop.seed_lo = (unsigned)seed; p.drop.seed_hi = (unsigned)(seed >> 32);
+    long blocks = (p.n8 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (bwd) hipLaunchKernelGGL(head_drop_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(head_drop_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
     return DP_LAUNCH_STATUS();
 }

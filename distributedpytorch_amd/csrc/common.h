@@ -46,6 +46,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Counter-based dropout: the keep decision of an element is a hash of (element index, seed), 16 bits per element,
+// so backward kernels RECOMPUTE it — no mask tensor.  thr = round(p·65536) (0 = off), scale = 1 / (1 − thr/65536).
+struct Drop { unsigned thr; float scale; unsigned seed_lo, seed_hi; };
+
+__device__ __forceinline__ unsigned drop_hash(unsigned lo, unsigned hi, const Drop& d) {
+    unsigned x = lo ^ d.seed_lo;
+    x *= 0xcc9e2d51u; x = (x << 15) | (x >> 17); x *= 0x1b873593u;
+    x ^= (hi ^ d.seed_hi) * 0x85ebca6bu;
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;      // murmur3 fmix32
+    return x;
+}
+
+// keep bits of the 8 elements of 16-byte chunk q (bit j = element j)
+__device__ __forceinline__ unsigned drop_keep8(long q, const Drop& d) {
+    const unsigned long long e = (unsigned long long)q * 4ull;
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned h = drop_hash((unsigned)(e + k), (unsigned)((e + k) >> 32), d);
+        keep |= (unsigned)((h & 0xffffu) >= d.thr) << (2 * k);
+        keep |= (unsigned)((h >> 16) >= d.thr) << (2 * k + 1);
+    }
+    return keep;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Deterministic mode (ops._backend.set_deterministic / DPAMD_DETERMINISTIC=1; defined in misc.hip): launchers

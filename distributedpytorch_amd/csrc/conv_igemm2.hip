@@ -74,7 +74,9 @@ struct Conv2Args {
     unsigned x_bytes, w_bytes;
     int ablate;             // diagnostics only (dp_conv_set_ablate): 1 = no LDS-DMA in the K loop,
                             // 4 = no fragment reads and no MFMA; results are garbage, the TIME tells the bound
-    int stag_slot, stag_cu, first_round;   // start-time stagger of the first round of blocks (see the kernel head)
+    int w_img, img_px;      // per-image weights (channel attention: a 1x1 convolution whose [Cout, Cin] matrix differs per
+                            //   image): elements between two images' weights and pixels per image (a multiple of the tile
+                            //   height, so a tile never straddles two images); w_img = 0: one weight tensor for all
 #ifdef DP_STAMP
     unsigned long long* dbg;   // diagnostic build only (tools/stamp_conv.py): 7 s_memtime + 2 s_memrealtime stamps per block (stride 16)
 #endif
@@ -90,14 +92,9 @@ struct Conv2Args {
 #define DP_STAMP_AT(i)
 #endif
 
-// Spreading a stage's LDS-DMA pieces over the MFMA groups of the K loop (what gained 4-6 % in the weight-gradient
-// kernel's 3-stage ring) is 1 % SLOWER here: with the 2-stage rings the tiles run, a piece issued late in step t has
-// less than a step left to land before step t + 1 waits for it (profiles/r2_conv_dma_spread_negative.log).  Off.
-#ifndef DP_SPREAD_DMA
-#define DP_SPREAD_DMA 0
-#endif
-constexpr int kSpreadMode = DP_SPREAD_DMA;      // 0 off, 1 every ring, 2 rings of three stages and more
-
+// (Spreading a stage's LDS-DMA pieces over the MFMA groups of the K loop — what gained 4-6 % in the weight-gradient
+// kernel's 3-stage ring — is 1 % SLOWER here: with 2-stage rings a piece issued late in step t has less than a step
+// left to land before step t + 1 waits for it; profiles/r2_conv_dma_spread_negative.log.  Not built.)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -145,8 +142,8 @@ __device__ __forceinline__ void lds_read16(i32x4v& dst, unsigned addr) {
 #define DP_BN_GRP(NR) ((NR) % 8 == 0 ? 8 : ((NR) % 6 == 0 ? 6 : ((NR) % 4 == 0 ? 4 : ((NR) % 3 == 0 ? 3 : ((NR) % 2 == 0 ? 2 : 1)))))
 #endif
 
-// PIPE: fragment reads are software-pipelined against the MFMAs by hand (see the K loop).
-template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64, bool PIPE = true>
+// Fragment reads are software-pipelined against the MFMAs by hand (see the K loop).
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2Args p) {
     constexpr int T = 64 * WGM * WGN;
     constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
@@ -172,21 +169,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     stamp_[9] = __builtin_amdgcn_s_getreg(63492);    // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
     stamp_[10] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
 #endif
-    // ---- de-phasing ----
-    // Blocks that share a CU (and the CUs of the chip) all start together and, doing identical work, stay in
-    // phase: everybody fills, everybody runs the K loop (L2->LDS and MFMA busy, HBM idle), everybody stores
-    // (HBM saturated, MFMA idle) — measured with tools/stamp_conv.py.  Delaying the blocks of the FIRST round by
-    // a fraction of a block's life, by wave slot (co-resident blocks) and by CU parity, makes later rounds
-    // overlap one block's epilogue with another's K loop; later blocks inherit the offset of the block whose
-    // slot they take.
-    if (p.stag_slot | p.stag_cu) {
-        if ((int)blockIdx.x < p.first_round) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(63492);
-            constexpr int WPS = T / 256;                              // waves of one block per SIMD
-            const int units = (int)((hw & 15u) / WPS) * p.stag_slot + (int)((hw >> 8) & 3u) * p.stag_cu;
-            for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
-        }
-    }
+    // (A start-time stagger of the first round of blocks by wave slot / CU — so that one block's store loop overlaps
+    // another's K loop — was measured at +-0.5 % of the step over 12 settings: README "De-phasing".  Not built.)
     DP_STAMP_AT(0);
 
     // ---- XCD-aware tile mapping (bijective for any grid size) ----
@@ -202,7 +186,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
     const int n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const bf16_raw* wimg = p.w_img ? p.w + (size_t)(m0 / p.img_px) * p.w_img : p.w;       // uniform
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wimg, 0, (int)p.w_bytes, 0x00020000);
 
     // ---- per-thread load geometry: lane -> (row rr of the round, physical 16-B chunk pc) ----
     const int pc = tid & (CPR - 1);
@@ -366,19 +351,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
 #ifdef DP_STAMP
         if (t == 0) DP_STAMP_AT(2);
 #endif
-        constexpr bool kSpreadDma = kSpreadMode == 1 || (kSpreadMode == 2 && NST >= 3);
         const bool do_issue = t + NST - 1 < ksteps && !(p.ablate & 1);      // uniform
         int ib = buf + NST - 1;
         if (ib >= NST) ib -= NST;
-        // PIPE: the stage's pieces go out between the MFMA groups below, SPREAD pieces per group, not as one burst
-        // of AR + BR wave instructions behind the barrier (every wave of the CU doing the same at the same moment
-        // fills the texture-address FIFOs and each piece then holds its wave for 100+ cycles; measured on the
-        // weight-gradient kernel: K loop -4...-6 %, profiles/r2_wgrad_dma_spread_stamps.txt)
-        if (do_issue && (!PIPE || !kSpreadDma)) issue_stage(ib);
+        if (do_issue) issue_stage(ib);
         if (p.ablate & 4) { if (++buf == NST) buf = 0; continue; }
-        if (PIPE) {
-            StageCtx sc{};
-            if (kSpreadDma && do_issue) sc = stage_begin(ib);
+        {
             // Left to itself hipcc sinks every fragment read to just before its first MFMA (2 reads, wait,
             // 8 MFMAs, 2 reads, wait, ...: the ISA of the first version), so each wave exposes an LDS
             // round trip per pair of pixel tiles and reads and MFMAs of a wave never overlap — the time of
@@ -420,17 +398,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                     else if (newer == PA) wait_lgkm<PA>();
                     else wait_lgkm<NI + PA>();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (kSpreadDma) {
-                        // this group's share of the next stage's pieces (the last group takes what is left)
-                        constexpr int NG = KK * G, PPG = (AR + BR + NG - 1) / NG;
-                        const int gi = kk * G + g;
-                        if (do_issue) {
-#pragma unroll
-                            for (int j = gi * PPG; j < (gi + 1 == NG ? AR + BR : (gi + 1) * PPG); ++j)
-                                if (j < AR + BR) stage_piece(sc, j);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
 #pragma unroll
                     for (int a = 0; a < PA; ++a)
 #pragma unroll
@@ -440,25 +407,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                                 acc[g * PA + a][ni], 0, 0, 0);
                 }
             }
-            if (kSpreadDma && do_issue) stage_end();
-        } else {
-        const unsigned char* St = smem + buf * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            const int chunk = kk == 0 ? ch0 : ch1;
-            bf16x8 wf[NI], xf[MI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                wf[ni] = *reinterpret_cast<const bf16x8*>(St + w_row_off + ni * (16 * ROWB) + chunk);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                xf[mi] = *reinterpret_cast<const bf16x8*>(St + x_row_off + mi * (16 * ROWB) + chunk);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
-        }
         }
         if (++buf == NST) buf = 0;
     }
@@ -734,34 +682,7 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
     constexpr int epi_bytes = BM * (BN * 2 + 8) + WGM * 2 * BN * 4;
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static const bool pipe = !(getenv("DPAMD_CONV_PIPE") && atoi(getenv("DPAMD_CONV_PIPE")) == 0);
-    if (p.stag_slot | p.stag_cu) {
-        static int slots = 0;                      // resident blocks of this instantiation on the whole chip
-        if (!slots) {
-            int bpc = 0, dev = 0, cus = 256;
-            const void* kf = unit ? (const void*)conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK>
-                                  : (const void*)conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false, BK>;
-            (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kf, T, lds) != hipSuccess || bpc < 1) bpc = 1;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            slots = bpc * cus;
-        }
-        p.first_round = slots;
-    }
-    if (!pipe) {
-        if (unit) {
-            auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK, false>;
-            static bool once = false;
-            if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
-        } else {
-            auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false, BK, false>;
-            static bool once = false;
-            if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
-        }
-        return DP_LAUNCH_STATUS();
-    }
+    if (p.w_img && p.img_px % BM != 0) return -2;          // a tile would straddle two images' weights
     if (unit) {
         auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK>;
         if (lds > 64 * 1024) {
@@ -782,12 +703,12 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
 
 }  // namespace
 
-// cfg: 1 = 128x128 4-wave 2-stage   2 = 128x128 4-wave 4-stage   3 = 256x128 8-wave 3-stage
-//      4 = 128x256 8-wave 3-stage   5 = 256x256 8-wave 2-stage   6 = 256x64 8-wave 3-stage
-//      7 = 128x64 4-wave 3-stage    8 = 160x128 / 9 = 192x128 4-wave 2-stage (tile-count quantisation)
-//      10 = 256x128 8-wave 2-stage   11 = 256x256 / 12 = 256x128 8-wave, 13 = 128x64 4-wave: 32-wide K steps, 4-stage ring
+// cfg: 1 = 128x128 4-wave 2-stage   3 = 256x128 8-wave 3-stage   4 = 128x256 8-wave 3-stage
+//      5 = 256x256 8-wave 2-stage   7 = 128x64 4-wave 3-stage    8 = 160x128 / 9 = 192x128 4-wave 2-stage
+//      (tile-count quantisation)    10 = 256x128 8-wave 2-stage  13 = 128x64 4-wave, 32-wide K steps, 4-stage ring (stem)
 //      14 = 128x128 (32-wide K, 36 KiB LDS, 4 blocks/CU)  15 = 128x64 (48 KiB, 3 blocks/CU)  16 = 192x128 (32-wide K,
-//      53 KiB, 3 blocks/CU)  17 = 256x128 / 18 = 128x256 8-wave (32-wide K, 72 KiB, 2 blocks = 16 waves/CU)
+//      53 KiB, 3 blocks/CU)
+//      (numbers 2, 6, 11, 12, 17, 18 were tiles no tuning run ever picked: removed in round 3)
 //      small-LDS tiles for short-K layers whose time is the store loop (1x1 data gradients
 //      with the fused BN-backward prologue read three tensors per output) — more resident blocks overlap one
 //      block's K loop with another's stores
@@ -815,17 +736,14 @@ thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
 thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
 thread_local const float* t_res_affine[2] = {nullptr, nullptr};   // set by dp_conv_igemm2ra
+thread_local int t_w_img = 0;    // set by dp_conv_igemm2pi
 int g_ablate = 0;
-int g_stag_slot = -1, g_stag_cu = -1;            // -1: read DPAMD_CONV_STAGGER ("slot,cu", units of 1024 cycles) once
 #ifdef DP_STAMP
 unsigned long long* g_dbg = nullptr;
 #endif
 }  // namespace
 
 DP_EXPORT int dp_conv_set_ablate(int mask) { g_ablate = mask; return 0; }
-DP_EXPORT int dp_conv_set_stagger(int slot_units, int cu_units) {
-    g_stag_slot = slot_units < 0 ? 0 : slot_units; g_stag_cu = cu_units < 0 ? 0 : cu_units; return 0;
-}
 #ifdef DP_STAMP
 DP_EXPORT int dp_conv_set_dbg(void* buf) { g_dbg = (unsigned long long*)buf; return 0; }
 #endif
@@ -863,13 +781,8 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S;
     p.ldx = ldx;
     p.ablate = g_ablate;
-    if (g_stag_slot < 0) {
-        int a = 0, b = 0;
-        const char* e = getenv("DPAMD_CONV_STAGGER");
-        if (e) sscanf(e, "%d,%d", &a, &b);
-        g_stag_slot = a < 0 ? 0 : a; g_stag_cu = b < 0 ? 0 : b;
-    }
-    p.stag_slot = g_stag_slot; p.stag_cu = g_stag_cu; p.first_round = 0;
+    p.w_img = t_w_img; p.img_px = Ho * Wo;
+    if (p.w_img && (!(R == 1 && S == 1) || sdiv != 1 || smul != 1 || t_ldx > 0)) return -1;
 #ifdef DP_STAMP
     p.dbg = g_dbg;
 #endif
@@ -880,23 +793,17 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     const bool unit = (R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && sdiv == 1 && ldx == Cin);
     switch (cfg) {
         case 1: return launch2<128, 128, 2, 2, 2, 2>(p, unit, st);
-        case 2: return launch2<128, 128, 2, 2, 4, 1>(p, unit, st);
         case 3: return launch2<256, 128, 4, 2, 3, 2>(p, unit, st);
         case 4: return launch2<128, 256, 2, 4, 3, 2>(p, unit, st);
         case 5: return launch2<256, 256, 2, 4, 2, 2>(p, unit, st);
-        case 6: return launch2<256, 64, 4, 2, 3, 2>(p, unit, st);
         case 7: return launch2<128, 64, 2, 2, 3, 1>(p, unit, st);
         case 8: return launch2<160, 128, 2, 2, 2, 2>(p, unit, st);
         case 9: return launch2<192, 128, 2, 2, 2, 2>(p, unit, st);
         case 10: return launch2<256, 128, 4, 2, 2, 2>(p, unit, st);
-        case 11: return launch2<256, 256, 2, 4, 4, 2, 32>(p, unit, st);
-        case 12: return launch2<256, 128, 4, 2, 4, 2, 32>(p, unit, st);
         case 13: return launch2<128, 64, 2, 2, 4, 1, 32>(p, unit, st);
         case 14: return launch2<128, 128, 2, 2, 2, 4, 32>(p, unit, st);
         case 15: return launch2<128, 64, 2, 2, 2, 3>(p, unit, st);
         case 16: return launch2<192, 128, 2, 2, 2, 3, 32>(p, unit, st);
-        case 17: return launch2<256, 128, 4, 2, 2, 4, 32>(p, unit, st);
-        case 18: return launch2<128, 256, 2, 4, 2, 4, 32>(p, unit, st);
         // (256x256 on FOUR waves — wave tile 128x128, accumulators in AGPRs, a third less fragment traffic — was
         // measured 2.4x SLOWER than case 5 on the K = 728 pointwise layers: 1150 vs 471 us, gpurun_out/n/shapes.log;
         // one wave per SIMD hides neither the LDS round trips nor the spills of its 512-register budget)
@@ -957,5 +864,17 @@ DP_EXPORT int dp_conv_igemm2w(const void* x, const void* w, void* y, const float
     const int rc = dp_conv_igemm2r(x, w, y, bias, stats, stat_reps, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
                                    pad_h, pad_w, dil_h, dil_w, ldy, cfg, nullptr, 0, st);
     t_ldx = 0;
+    return rc;
+}
+
+// A 1x1 convolution whose weights differ PER IMAGE (w: [N, Cout, Cin]; channel attention's attn · X) as ONE launch:
+// tile rows never straddle images (Ho*Wo a multiple of the tile height, else -2), so a block picks its image's matrix.
+DP_EXPORT int dp_conv_igemm2pi(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int cfg,
+                               const void* res, hipStream_t st) {
+    if ((long)N * Cout * Cin * 2 >= (1L << 31) - (1L << 24)) return -4;
+    t_w_img = Cout * Cin;
+    const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Hi, Wi, Cout, 1, 1, 1, 1, 0, 0, 1, 1,
+                                   Cout, cfg, res, Cout, st);
+    t_w_img = 0;
     return rc;
 }

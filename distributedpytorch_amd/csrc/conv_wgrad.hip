@@ -61,144 +61,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int off0, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // ---- block → (split, n-tile, k-tile); XCD-aware so one XCD's blocks share a pixel range ----
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tiles = p.tiles_k * p.tiles_n;
-    const int split = bid / tiles;
-    const int tile = bid - split * tiles;
-    const int tile_k = tile % p.tiles_k, tile_n = tile / p.tiles_k;
-    const int k0 = tile_k * TM, n0 = tile_n * TN;
-    const int p_begin = split * p.px_per_split;
-    const int p_end = min(p.P, p_begin + p.px_per_split);
-    const int nsteps = (p_end - p_begin + TP - 1) / TP;
-
-    // ---- load geometry: a wave-instruction fills 4 rows × 256 B ----
-    const int pc = lane & 15;                       // physical chunk
-    const int rsub = lane >> 4;                     // row within the 4-row group
-    const int fsw = (rsub << 2) | wave;             // f(row): row&3 = rsub, (row>>2)&3 = wave
-    const int lc = pc ^ fsw;                        // logical chunk fetched by this lane
-    const bf16_raw* zero = reinterpret_cast<const bf16_raw*>(g_zero_page_w) + (pc & 7) * 8;
-
-    // dy operand: channel k0 + lc*8
-    const int kch = k0 + lc * 8;
-    const unsigned k_ok = (unsigned)(kch < p.Cout);
-    // x operand: flattened weight-row index → (tap, c)
-    const int flat = n0 + lc * 8;
-    const unsigned n_ok = (unsigned)(flat < p.NF);
-    const int tap = flat / p.Cin;
-    const int cch = flat - tap * p.Cin;
-    const int tr = tap / p.S, ts = tap - tr * p.S;
-    const int tdy = tr * p.dil_h - p.pad_h, tdx = ts * p.dil_w - p.pad_w;
-
-    // per-round pixel state (row = round*16 + wave*4 + rsub), advanced incrementally by TP per step
-    int px[4], pox[4], poy[4], pn[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        px[i] = p_begin + i * 16 + wave * 4 + rsub;
-        pox[i] = px[i] % p.Wo;
-        const int t = px[i] / p.Wo;
-        poy[i] = t % p.Ho;
-        pn[i] = t / p.Ho;
-    }
-    const int adv_x = TP % p.Wo, adv_y = TP / p.Wo;
-
-    auto issue_stage = [&](int buf) {
-        unsigned char* dbase = smem + buf * STAGE + wave * 1024;   // dy tile
-        unsigned char* xbase = dbase + TILE_BYTES;                 // x tile
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned p_ok = (unsigned)(px[i] < p_end);
-            const unsigned okd = p_ok & k_ok;
-            glds16w(okd ? p.dy + (px[i] * p.Cout + kch) : zero, dbase + i * 4096);
-            const int iy = poy[i] * p.stride_h + tdy, ix = pox[i] * p.stride_w + tdx;
-            const unsigned okx = p_ok & n_ok & (unsigned)((unsigned)iy < (unsigned)p.Hi) &
-                                 (unsigned)((unsigned)ix < (unsigned)p.Wi);
-            glds16w(okx ? p.x + (((pn[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + cch) : zero, xbase + i * 4096);
-            // advance this row's pixel by TP
-            px[i] += TP;
-            pox[i] += adv_x; poy[i] += adv_y;
-            if (pox[i] >= p.Wo) { pox[i] -= p.Wo; poy[i] += 1; }
-            while (poy[i] >= p.Ho) { poy[i] -= p.Ho; pn[i] += 1; }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    // ---- fragment read geometry (see file header): group g = lane>>4, q = (lane&15)>>2, pp = lane&3
-    const int wm = wave >> 1, wn = wave & 1;             // 2×2 waves, each 64(k) × 64(n)
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    // row (pixel) inside a 16-pixel k-block for read rd: 8*(g>>1) + 4*rd + q
-    // physical chunk = (cb/8 + 2*(g&1) + (pp>>1)) ^ ((q<<2) | ((2*(g>>1) + rd) & 3))
-    int offA[2][2], offB[2][2];                          // [sub-tile][rd]
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int row = 8 * (g >> 1) + 4 * rd + q;
-            const int f = (q << 2) | ((2 * (g >> 1) + rd) & 3);
-            const int chA = ((wm * 64 + t * 32) >> 3) + 2 * (g & 1) + (pp >> 1);
-            const int chB = ((wn * 64 + t * 32) >> 3) + 2 * (g & 1) + (pp >> 1);
-            offA[t][rd] = row * 256 + ((chA ^ f) << 4) + (pp & 1) * 8;
-            offB[t][rd] = row * 256 + ((chB ^ f) << 4) + (pp & 1) * 8;
-        }
-    }
-
-    if (nsteps > 0) issue_stage(0);
-    for (int t = 0; t < nsteps; ++t) {
-        const int buf = t & 1;
-        __syncthreads();
-        if (t + 1 < nsteps) issue_stage(buf ^ 1);
-        const unsigned char* Ds = smem + buf * STAGE;
-        const unsigned char* Xs = Ds + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < TP / 16; ++kk) {
-            const int kb = kk * 16 * 256;   // 16 pixel rows per MFMA K block
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = tr_frag(Ds + kb, offA[i][0], offA[i][1]);
-                bfr[i] = tr_frag(Xs + kb, offB[i][0], offB[i][1]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ---- split-K combine: fp32 atomics, 2 × 128-B contiguous segments per wave-instruction ----
-    const int frow = lane & 31, fhalf = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + frow;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-                if (row < p.Cout && col < p.NF) atomicAdd(p.dw + (long)row * p.NF + col, acc[i][j][e]);
-            }
-        }
-    }
-}
+// (The first-generation kernel — global_load_lds with 64-bit addresses, 2-stage ring, no windows — was the route
+// for tensors beyond the 32-bit offsets; ops._hip_conv cuts such batches into image chunks on the kernel below
+// since round 2, nothing reached it any more: removed in round 3.)
 
 
 // ------------------------------------------------------------------------------------------------
@@ -683,14 +548,6 @@ DP_EXPORT int dp_wgrad_set_dbg(void* buf) { g_wg_dbg = (unsigned long long*)buf;
 // splits: 0 = auto.  dw must be zero-initialised (or hold a gradient to accumulate into).
 namespace {
 thread_local int t_wg_ldx = 0;     // set by dp_conv_wgrad_win
-int g_wg_mfma = 0;                 // 0: read DPAMD_WGRAD_MFMA at the first launch
-}
-
-// tests / tools: MFMA shape of the two-group weight-gradient kernel, 16 (16x16x32) or 32 (32x32x16); returns the old one
-DP_EXPORT int dp_wgrad_set_mfma(int shape) {
-    const int old = g_wg_mfma;
-    if (shape == 16 || shape == 32) g_wg_mfma = shape;
-    return old;
 }
 
 DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
@@ -707,9 +564,10 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     p.stride_h = stride_h; p.stride_w = stride_w; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
     p.NF = R * S * Cin;
     // two wave groups per block (256 output channels, shared x tile) when the channels fill them
-    static const int force_g = getenv("DPAMD_WGRAD_G") ? atoi(getenv("DPAMD_WGRAD_G")) : 0;
     const long x_bytes0 = (long)N * Hi * Wi * ldx * 2;
-    const bool gen2_ok = !(reserved == 1 || x_bytes0 >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24));
+    (void)reserved;
+    // 32-bit offsets of the LDS-DMA loads: the caller cuts larger batches into image chunks (ops._hip_conv.wgrad)
+    if (x_bytes0 >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24)) return -4;
     // G = 2 also for channel counts that do not fill the last 256-channel block (Xception's 728 = 2.84 x 256): the
     // kernel's loads and its combine are bounds-checked per 128-channel sub-tile, and what the ragged block wastes
     // (768 vs 728 rows) the shared x tile and the 3-deep ring pay back many times — the 4-wave G = 1 kernel ran the
@@ -717,7 +575,7 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     // 256 would add more than 1/8 to the rows the 128-blocks cover.
     const int pad256 = (Cout + 2 * TM - 1) / (2 * TM) * (2 * TM), pad128 = (Cout + TM - 1) / TM * TM;
     const bool g2_shape = Cout > TM && pad256 * 8 <= pad128 * 9;
-    const int G = (gen2_ok && g2_shape && force_g != 1) ? 2 : 1;
+    const int G = g2_shape ? 2 : 1;
     p.tiles_k = (Cout + TM * G - 1) / (TM * G);
     p.tiles_n = (p.NF + TN - 1) / TN;
     const int tiles = p.tiles_k * p.tiles_n;
@@ -729,8 +587,7 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
         // split-K combine moves splits·|dW| bytes through fp32 atomics at ~1.3 TB/s chip-wide
         // (MI355X_MICROARCH: global float atomics) — the term the first heuristic ignored: it asked
         // for 1536 blocks and spent 70 % of a layer-3 wgrad in atomics.
-        static const double atomic_w = getenv("DPAMD_WGRAD_ATOMIC_W") ? atof(getenv("DPAMD_WGRAD_ATOMIC_W")) : 1.0;
-        const double dw_mb = atomic_w * (double)Cout * p.NF * 4.0 / 1e6;
+        const double dw_mb = (double)Cout * p.NF * 4.0 / 1e6;
         double best = 1e30;
         int best_s = 1;
         const int max_s = steps_total < 512 ? steps_total : 512;
@@ -752,12 +609,6 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     const long nwg = (long)tiles * p.splits;
     if (nwg > 0x7fffffffL) return -4;
     const long x_bytes = (long)N * Hi * Wi * ldx * 2;
-    if (ldx != Cin && (reserved == 1 || x_bytes >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24)))
-        return -2;                                   // windows are a second-generation feature
-    if (reserved == 1 || x_bytes >= (1L << 31) - (1L << 24) || P * Cout * 2 >= (1L << 31) - (1L << 24)) {
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, p);
-        return DP_LAUNCH_STATUS();
-    }
     Wgrad2Args q{};
     q.dy = p.dy; q.x = p.x; q.dw = p.dw; q.P = p.P; q.Hi = Hi; q.Wi = Wi; q.Cin = Cin; q.Ho = Ho; q.Wo = Wo;
     q.Cout = Cout; q.R = R; q.S = S; q.stride_h = stride_h; q.stride_w = stride_w; q.pad_h = pad_h; q.pad_w = pad_w;
@@ -767,14 +618,11 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
     q.dbg = g_wg_dbg;
 #endif
     const bool unit = R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1 && ldx == Cin;
-    static const int ring = getenv("DPAMD_WGRAD_RING") ? atoi(getenv("DPAMD_WGRAD_RING")) : 3;
-    // 16 (default): measured against 32 on one box, R101 B128: 952.8 / 950.5 vs 946.6 / 947.1 img/s; alone the kernels
-    // tie (the K loop is bound by the operand stream, the 64-byte atomic segments of the 16 x 16 tiles cost what the
-    // higher clock — 1.9-2.1 vs 1.7-1.9 GHz — gives back), gpurun_out/au
-    if (g_wg_mfma == 0) g_wg_mfma = getenv("DPAMD_WGRAD_MFMA") ? atoi(getenv("DPAMD_WGRAD_MFMA")) : 16;
-    const int mfma_shape = g_wg_mfma;
-    if (G == 2 && ring == 3 && mfma_shape == 16) {
-        constexpr int lds3 = 3 * 3 * TILE_BYTES;
+    // Two wave groups: three-stage ring, 16x16x32 MFMA.  (Measured against the 32x32x16 shape on one box, R101 B128:
+    // 952.8 / 950.5 vs 946.6 / 947.1 img/s — alone the kernels tie, the chip holds a higher clock on 16x16x32 — and
+    // against the two-stage ring: -4...-6 % K loop.  Both alternatives were removed in round 3.)
+    if (G == 2) {
+        constexpr int lds3 = 3 * 3 * TILE_BYTES;      // 144 KiB: three stages, one block per CU
         static bool once16 = false;
         if (!once16) {
             (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<true, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
@@ -783,30 +631,6 @@ DP_EXPORT int dp_conv_wgrad(const void* dy, const void* x, void* dw, int N, int 
         }
         if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 2, 3, true>), dim3((unsigned)nwg), dim3(2 * kThreads), lds3, st, q);
         else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2, 3, true>), dim3((unsigned)nwg), dim3(2 * kThreads), lds3, st, q);
-        return DP_LAUNCH_STATUS();
-    }
-    if (G == 2 && ring == 3) {
-        constexpr int lds3 = 3 * 3 * TILE_BYTES;      // 144 KiB: three stages, one block per CU
-        static bool once3 = false;
-        if (!once3) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-            once3 = true;
-        }
-        if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 2, 3>), dim3((unsigned)nwg), dim3(2 * kThreads), lds3, st, q);
-        else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2, 3>), dim3((unsigned)nwg), dim3(2 * kThreads), lds3, st, q);
-        return DP_LAUNCH_STATUS();
-    }
-    if (G == 2) {
-        constexpr int lds2 = 2 * 3 * TILE_BYTES;      // 96 KiB
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-            once = true;
-        }
-        if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 2>), dim3((unsigned)nwg), dim3(2 * kThreads), lds2, st, q);
-        else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2>), dim3((unsigned)nwg), dim3(2 * kThreads), lds2, st, q);
         return DP_LAUNCH_STATUS();
     }
     if (unit) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 1>), dim3((unsigned)nwg), dim3(kThreads), 2 * STAGE, st, q);

@@ -13,10 +13,9 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..ops import conv_bn_act, BatchNorm2d, Conv2d, bilinear_resize
-from ..ops.attention import channel_attention, position_attention
+from ..ops.attention import channel_attention, head_dropout, position_attention
 from .resnet import ResNet
 
 
@@ -60,8 +59,8 @@ class _DropCls(nn.Module):
         super().__init__()
         self.add_module("1", Conv2d(cin, nclass, 1))
 
-    def forward(self, x, training):
-        return getattr(self, "1")(F.dropout(x, 0.1, training))
+    def forward(self, x):              # x: already dropped (DANetHead.forward: one fused pass for the three branches)
+        return getattr(self, "1")(x)
 
 
 class DANetHead(nn.Module):
@@ -76,7 +75,8 @@ class DANetHead(nn.Module):
     def forward(self, x, training: bool):
         sa = self.conv51(self.sa(self.conv5a(x)))
         sc = self.conv52(self.sc(self.conv5c(x)))
-        return (self.conv8(sa + sc, training), self.conv6(sa, training), self.conv7(sc, training))
+        d_sa, d_sc, d_sum = head_dropout(sa, sc, 0.1, training)
+        return (self.conv8(d_sum), self.conv6(d_sa), self.conv7(d_sc))
 
 
 class DANet(nn.Module):

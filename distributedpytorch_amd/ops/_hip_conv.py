@@ -33,6 +33,7 @@ def _lib():
         lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
         lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 9 + [I, V]
         lib.dp_conv_igemm2ra.argtypes = [V, V, V] + [I] * 16 + [V] * 4
+        lib.dp_conv_igemm2pi.argtypes = [V, V, V] + [I] * 6 + [V, V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -62,7 +63,7 @@ def _round8(c: int) -> int:
 # BN-backward sums and weight gradients accumulate by atomics into the same buffers, so the chunks need no combine
 # step.  (Round 1 sent such layers - per-GPU batch > 224 of the headline model - to the first-generation kernel.)
 _OFFSET_LIMIT = (1 << 31) - (1 << 24)
-_CHUNKING = os.environ.get("DPAMD_CONV_BATCH_CHUNKS", "1") != "0"
+_CHUNKING = True          # module switches like this one are for tests / tools to patch, not environment knobs
 
 
 def _images_per_launch(n: int, *streamed) -> int:
@@ -156,6 +157,64 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
     return y
 
 
+def igemm_per_image(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[b] = x[b] · w[b]ᵀ (+ residual[b])``: a 1×1 convolution whose [Cout, Cin] matrix differs per image
+    (``w``: contiguous bf16 [N, Cout, Cin]), as ONE launch of the implicit-GEMM kernel — a block's rows never
+    straddle two images, so it points its weight descriptor at its image's matrix.  (Was a Python loop of N
+    launches: ~130 per DANet step at batch 32.)"""
+    n, cin, h, wd = x.shape
+    if w.dim() != 3 or w.shape[0] != n or w.shape[2] != cin or w.dtype != torch.bfloat16 or not w.is_contiguous():
+        raise ValueError("igemm_per_image: w must be contiguous bf16 [N, Cout, Cin]")
+    cout = w.shape[1]
+    if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last) or cin % 8 or cout % 8:
+        raise ValueError("igemm_per_image: x must be channels-last bf16 with Cin, Cout multiples of 8")
+    px = h * wd
+    if px % 128:
+        raise ValueError(f"igemm_per_image: {h}x{wd} positions per image is not a multiple of the 128-row tile")
+    if x.numel() * 2 >= _OFFSET_LIMIT:
+        raise ValueError("igemm_per_image: activation beyond the kernel's 32-bit offsets; split the batch")
+    y = out if out is not None else torch.empty((n, cout, h, wd), dtype=torch.bfloat16, device=x.device,
+                                                memory_format=torch.channels_last)
+    for t, name in ((y, "out"), (residual, "residual")):
+        if t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != (n, cout, h, wd) or t.data_ptr() % 16
+                              or not t.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError(f"igemm_per_image: {name} must be a channels-last bf16 tensor of the result's shape")
+
+    def run(cfg):
+        return _lib().dp_conv_igemm2pi(B.ptr(x), B.ptr(w), B.ptr(y), n, h, wd, cin, cout, cfg, B.ptr(residual),
+                                       B.stream_ptr())
+    key = ("per_image", n, h, wd, cin, cout, residual is not None)
+    cfg = _TUNED.get(key)
+    if cfg is None:
+        if B.deterministic() or not _AUTOTUNE:
+            cfg = 1
+        else:
+            cands = [c for c in (5, 10, 3, 4, 1, 14) if px % (256 if c in (5, 10, 3) else 128) == 0]
+            cfg = _TUNED[key] = _agreed(lambda: _time_best(cands, run, x.device))
+            _save_tuned()
+    B.check(run(cfg), "conv_igemm2pi")
+    return y
+
+
+def _time_best(cands, run, device) -> int:
+    """Fastest of ``cands`` for ``run(cfg) -> status`` (3 timed launches each after one untimed)."""
+    best, best_t = cands[-1], float("inf")
+    for c in cands:
+        if run(c) != 0:
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            run(c)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = c, t
+    return best
+
+
 # ---- tile-configuration choice -------------------------------------------------------------------
 # Which tile wins depends on how the tile COUNT quantises against 256 CUs x blocks/CU for the actual
 # batch (measured: the same layer-3 conv takes 35 us at 546 tiles and 22 us at 512), so the choice is
@@ -163,11 +222,10 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
 # statistics go to a scratch buffer meanwhile), the fastest is cached for the life of the process.
 _FORCED_CFG = int(os.environ["DPAMD_CONV_CFG"]) if "DPAMD_CONV_CFG" in os.environ else None
 _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
-# 11-13 (32-wide K steps, 4-stage ring) are selectable but not tried: measured 8-10 % slower than their
-# 64-wide 2-stage counterparts on every R101 layer at batch 128 (profiles/r1_conv_cfg_sweep_b128.log)
 # 14-16: small-LDS tiles (3-4 resident blocks per CU) for short-K layers bound by their store loop: 16 wins 23
-# and 15 five of the 69 headline problems (gpurun_out/s90, s91: 944-952 img/s against 928 without them on the
-# same box).  17 / 18 (their 8-wave forms) were never picked in three tuning runs: selectable, not tried.
+# and 15 five of the 69 headline problems (944-952 img/s against 928 without them on the same box).  The tiles no
+# tuning run ever picked (32-wide-K 4-stage rings 11/12, 8-wave small-LDS 17/18, 2, 6) were removed in round 3;
+# 13 stays for the stem (profiles/r1_conv_cfg_sweep_b128.log has the sweep).
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 14, 15, 16, 0)
 _TUNED: dict = {}
 _TUNE_COUNTS = {"packaged": 0, "measured_here": 0, "timed_on_this_rank": 0}
@@ -201,9 +259,9 @@ def _load_tuned(path: str) -> None:
 # majority choice of three autotune runs (tools/merge_tune.py; gpurun_out/s91).  Every rank then runs the SAME tiles from the
 # first step — per-rank tuning noise flips near-ties (20 of 101 problems differed between runs), and under
 # data parallelism the slowest rank's choice gates every step.  Problems not in the table are measured as
-# before; DPAMD_CONV_TUNE_TABLE=0 ignores the table.
+# before.
 _TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
-if os.environ.get("DPAMD_CONV_TUNE_TABLE", "1") != "0" and os.path.isfile(_TABLE):
+if os.path.isfile(_TABLE):
     _load_tuned(_TABLE)
     _TUNE_COUNTS["packaged"] = len(_TUNED)
 # optional cross-process cache of the measured choices (JSON): set DPAMD_CONV_TUNE_FILE
@@ -412,10 +470,8 @@ def dw_row_blocks(n: int, hi: int, wi: int, ho: int, wo: int) -> int:
 # (dgrad_bn_fused): the separate bn_bwd_reduce pass over dy and x disappears.  Measured A/B on one box
 # (gpurun_out/s80, s81): B128 905-907 vs 880-882 img/s, B64 864 vs 858, B32 809 vs 809 (the first version,
 # at B32 and before the residual/fan-out gradients moved into the store loop, was 1 % slower:
-# profiles/r1_bn_prologue_ab_b32.log).  DPAMD_BN_PROLOGUE=0 restores the separate reduction kernel.
-_BN_PROLOGUE = os.environ.get("DPAMD_BN_PROLOGUE", "1") != "0"
-# DPAMD_WGRAD_GEN=1 selects the first-generation weight-gradient kernel (A/B runs, bisection)
-_WGRAD_GEN1 = 1 if os.environ.get("DPAMD_WGRAD_GEN", "2") == "1" else 0
+# profiles/r1_bn_prologue_ab_b32.log).  _BN_PROLOGUE = False restores the separate reduction kernel.
+_BN_PROLOGUE = True
 
 
 def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None, splits: int = 0) -> torch.Tensor:
@@ -433,13 +489,13 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
         dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device,
                          memory_format=torch.channels_last).zero_()
     nper = _images_per_launch(n, x, dy)
-    if nper < n and not _WGRAD_GEN1:
+    if nper < n:
         for n0 in range(0, n, nper):         # split-K over image chunks: every launch adds into the same dw
             wgrad(dy[n0:n0 + nper], x[n0:n0 + nper], wshape, stride, pad, dil, out=dw, splits=splits)
         return dw
     if B.deterministic():
         splits = 1                       # one block per output tile: its atomics meet a zero or stream-ordered sum
-    elif splits == 0 and _AUTOTUNE and not _WGRAD_GEN1:
+    elif splits == 0 and _AUTOTUNE:
         key = ("wgrad", n, hi, wi, cin, ho, wo, cout, r, s, tuple(stride), tuple(pad), tuple(dil))
         splits = _TUNED.get(key)
         if splits is None:
@@ -447,7 +503,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, wshape, stride, pad, dil, out=None,
                 lambda: _autotune_wgrad(dy, x, dw, (n, hi, wi, cin, ho, wo, cout, r, s), stride, pad, dil))
             _save_tuned()
     B.check(_lib().dp_conv_wgrad(B.ptr(dy), B.ptr(x), B.ptr(dw), n, hi, wi, cin, ho, wo, cout, r, s,
-                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, _WGRAD_GEN1,
+                                 stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], splits, 0,
                                  B.stream_ptr()),
             "conv_wgrad")
     return dw
@@ -463,7 +519,7 @@ def _autotune_wgrad(dy, x, dw, geom, stride, pad, dil, runner=None) -> int:
     lib, stream = _lib(), B.stream_ptr()
     # blocks own 256 output channels when Cout fills them (csrc/conv_wgrad.hip, G = 2), else 128
     pad256, pad128 = (cout + 255) // 256 * 256, (cout + 127) // 128 * 128
-    tk = 256 if (cout > 128 and pad256 * 8 <= pad128 * 9 and os.environ.get("DPAMD_WGRAD_G") != "1") else 128
+    tk = 256 if (cout > 128 and pad256 * 8 <= pad128 * 9) else 128
     tiles = ((cout + tk - 1) // tk) * ((r * s * cin + 127) // 128)
     steps_total = (n * ho * wo + 63) // 64
     cands = [0]
@@ -625,11 +681,11 @@ class _ConvIGemm(torch.autograd.Function):
 # filter ROW becomes one tap: the S*4 <= 32 contiguous elements to the right of a pixel are that
 # pixel's "channels" (overlapping windows, pixel stride ldx = 4).  7 taps of 32, second-generation
 # kernels for forward and weight gradient, fused BN statistics as everywhere else.
-_DW_WGRAD_AUX = os.environ.get("DPAMD_DW_WGRAD_AUX", "1") != "0"   # depthwise weight gradients on the aux stream
-_SKIP_WGRAD = os.environ.get("DPAMD_SKIP_WGRAD") == "1"     # diagnostics: invalid training, timing only
-_SKIP_DW_WGRAD = os.environ.get("DPAMD_SKIP_DW_WGRAD") == "1"   # same, depthwise weight gradients
+_DW_WGRAD_AUX = True   # depthwise weight gradients on the aux stream
+_SKIP_WGRAD = False       # diagnostics (tools patch it): invalid training, timing only
+_SKIP_DW_WGRAD = False    # same, depthwise weight gradients
 _STEM_WINDOW = 32
-_STEM = os.environ.get("DPAMD_STEM_WINDOW", "1") != "0"
+_STEM = True
 
 
 def stem_window_ok(x, weight, stride, padding, dilation) -> bool:

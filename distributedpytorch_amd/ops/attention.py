@@ -36,6 +36,7 @@ def _lib():
         lib.dp_cam_softmax_fwd.argtypes = [V, V, V, V, L, I, V]
         lib.dp_cam_softmax_bwd.argtypes = [V, V, V, V, V, L, I, V]
         lib.dp_cam_mat.argtypes = [V, I, V, I, I, F, F, V]
+        lib.dp_head_dropout.argtypes = [V] * 6 + [L, ctypes.c_uint, ctypes.c_ulonglong, I, V]
         _sigs = True
     return lib
 
@@ -63,9 +64,11 @@ def channel_attention_reference(x, gamma):
 
 
 # ------------------------------------------------------------------------------------------ position attention
-def _pam_supported(q, k, v) -> bool:
-    return (B.use_hip(v) and v.dtype == torch.bfloat16 and q.shape[1] == 64 and k.shape[1] == 64
-            and v.shape[1] == 512)
+def _pad_channels(t, c):
+    """Zero channels appended up to ``c`` (channels-last result; autograd slices the gradient back)."""
+    if t.shape[1] == c:
+        return t
+    return torch.nn.functional.pad(t, (0, 0, 0, 0, 0, c - t.shape[1])).contiguous(memory_format=torch.channels_last)
 
 
 class _PositionAttention(torch.autograd.Function):
@@ -110,17 +113,36 @@ class _PositionAttention(torch.autograd.Function):
 
 def position_attention(q, k, v, x, gamma):
     """``γ · softmax(qᵀk) v + x`` over the H·W positions; all tensors [n, ·, h, w]."""
-    if _pam_supported(q, k, v):
-        return _PositionAttention.apply(q, k, v, x, gamma)
-    return position_attention_reference(q, k, v, x, gamma)
+    if not (B.use_hip(v) and v.dtype == torch.bfloat16):
+        return position_attention_reference(q, k, v, x, gamma)       # CPU tensors / the stock-op backend / fp32
+    # The kernels take 64 q/k channels and 512 value channels (DANet on ResNet-50/101).
+    # Other widths run the SAME kernels on zero-padded operands — exact: zero q/k channels add nothing to qᵀk, zero
+    # value channels give zero outputs, which are sliced off again.  There is no quiet switch to the (H·W)² map.
+    d, c = q.shape[1], v.shape[1]
+    if d > 64 or k.shape[1] != d:
+        raise NotImplementedError(f"position attention kernels: q/k with at most 64 channels (got {d}, {k.shape[1]}); "
+                                  "set_backend('torch') runs the plain formulation")
+    cp = (c + 511) // 512 * 512                    # the backward kernel keeps whole 512-wide value rows resident
+    q, k, v, x = _pad_channels(q, 64), _pad_channels(k, 64), _pad_channels(v, cp), _pad_channels(x, cp)
+    if cp == 512:
+        y = _PositionAttention.apply(q, k, v, x, gamma)
+    else:                                          # wider values: 512 channels at a time (autograd sums dq, dk)
+        cl = torch.channels_last
+        y = torch.cat([_PositionAttention.apply(q, k, v[:, i:i + 512].contiguous(memory_format=cl),
+                                                x[:, i:i + 512].contiguous(memory_format=cl), gamma)
+                       for i in range(0, cp, 512)], dim=1)
+    return y if cp == c else y[:, :c]
 
 
 # ------------------------------------------------------------------------------------------ channel attention
 def _per_image_1x1(x, w, residual, out):
     """out[b] = x[b] · w[b]ᵀ (+ residual[b]) for every image: the implicit-GEMM conv kernel as a 1×1 convolution
-    whose weights differ per image (w: [n, Cout, Cin] bf16)."""
+    whose weights differ per image (w: [n, Cout, Cin] bf16) — one launch for the whole batch; image by image only
+    where a tile would straddle two images (positions per image not a multiple of 128)."""
     from . import _hip_conv
     n, c, h, wd = x.shape
+    if (h * wd) % 128 == 0:
+        return _hip_conv.igemm_per_image(x, w, residual, out)
     for b in range(n):
         _hip_conv.igemm(x[b:b + 1], w[b].view(w.shape[1], w.shape[2], 1, 1), (h, wd), 1, 1, (0, 0), (1, 1),
                         residual=None if residual is None else residual[b:b + 1], out=out[b:b + 1])
@@ -175,6 +197,46 @@ class _ChannelAttention(torch.autograd.Function):
 
 def channel_attention(x, gamma):
     """``γ · softmax(max − X Xᵀ) X + x`` over channels; x [n, C, h, w]."""
-    if B.use_hip(x) and x.dtype == torch.bfloat16 and x.shape[1] % 128 == 0:
-        return _ChannelAttention.apply(x, gamma)
-    return channel_attention_reference(x, gamma)
+    if not (B.use_hip(x) and x.dtype == torch.bfloat16):
+        return channel_attention_reference(x, gamma)                  # CPU tensors / the stock-op backend / fp32
+    if x.shape[1] % 128:
+        # (padding is NOT exact here: a zero channel would take part in every row's softmax)
+        raise NotImplementedError(f"channel attention kernels: channels must be a multiple of 128 (got {x.shape[1]}); "
+                                  "set_backend('torch') runs the plain formulation")
+    return _ChannelAttention.apply(x, gamma)
+
+
+# ------------------------------------------------------------------------------------------ head dropouts
+class _HeadDropout(torch.autograd.Function):
+    """(drop(sa), drop(sc), drop(sa + sc)) with three independent masks in one pass; masks recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, sa, sc, thr, seed):
+        sa, sc = as_nhwc(sa), as_nhwc(sc)
+        o = [torch.empty_like(sa, memory_format=torch.channels_last) for _ in range(3)]
+        B.check(_lib().dp_head_dropout(B.ptr(sa), B.ptr(sc), None, B.ptr(o[0]), B.ptr(o[1]), B.ptr(o[2]), sa.numel(),
+                                       thr, seed, 0, B.stream_ptr()), "head_dropout")
+        ctx.key = (thr, seed)
+        return o[0], o[1], o[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        g = [as_nhwc(t) for t in (g0, g1, g2)]
+        da, dc = torch.empty_like(g[0], memory_format=torch.channels_last), \
+            torch.empty_like(g[0], memory_format=torch.channels_last)
+        B.check(_lib().dp_head_dropout(B.ptr(g[0]), B.ptr(g[1]), B.ptr(g[2]), B.ptr(da), B.ptr(dc), None, da.numel(),
+                                       ctx.key[0], ctx.key[1], 1, B.stream_ptr()), "head_dropout_bwd")
+        return da, dc, None, None
+
+
+def head_dropout(sa, sc, p: float, training: bool):
+    """DANet's head feeds ``drop(sa)``, ``drop(sc)`` and ``drop(sa + sc)`` to its three classifiers
+    (models/danet.py); returns them in that order."""
+    if not training or p <= 0.0:
+        return sa, sc, sa + sc
+    if B.use_hip(sa) and sa.dtype == torch.bfloat16 and sa.shape == sc.shape and sa.numel() % 8 == 0:
+        from .batchnorm import _dropout_key
+        thr, seed = _dropout_key(p)
+        return _HeadDropout.apply(sa, sc, thr, seed)
+    F = torch.nn.functional
+    return F.dropout(sa, p, True), F.dropout(sc, p, True), F.dropout(sa + sc, p, True)

@@ -27,9 +27,9 @@ import os
 
 from . import _backend as B
 
-_FUSE_DROPOUT = os.environ.get("DPAMD_FUSE_DROPOUT", "1") != "0"
-# DPAMD_BN_MASK_BITS=0: residual blocks keep no positivity bit mask (the consumer re-reads the activation)
-_MASK_BITS = os.environ.get("DPAMD_BN_MASK_BITS", "1") != "0"
+_FUSE_DROPOUT = True
+# False: residual blocks keep no positivity bit mask (the consumer re-reads the activation)
+_MASK_BITS = True
 
 
 # --------------------------------------------------------------------------------------
@@ -96,9 +96,9 @@ def _small_all_reduce(packed: torch.Tensor, pg) -> None:
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=pg)
 
 
-# DPAMD_SYNCBN_FORCE=1 (with DPAMD_DDP_FORCE=1): the statistics collectives run on a ONE-rank group too — the launch
-# choreography of synchronised BatchNorm measured on a single GPU (timing only: the sums are unchanged)
-_FORCE_SYNC = os.environ.get("DPAMD_SYNCBN_FORCE", "0") != "0"
+# DPAMD_DDP_FORCE=1 (a forced ONE-rank group, parallel.ddp) with --sync-bn: the statistics collectives run too — the
+# launch choreography of synchronised BatchNorm measured on a single GPU (timing only: the sums are unchanged)
+_FORCE_SYNC = os.environ.get("DPAMD_DDP_FORCE", "0") != "0"
 
 
 def _group_active(group) -> bool:

@@ -21,7 +21,7 @@ import os
 
 from . import _backend as B
 
-ENABLED = os.environ.get("DPAMD_INPLACE_CONCAT", "1") != "0"
+ENABLED = True
 
 Slot = Tuple[torch.Tensor, int, int]          # (buffer, channel offset, channels)
 

@@ -42,7 +42,7 @@ _FOLD = os.environ.get("DPAMD_SEPCONV_FOLD", "1") != "0"
 # backward schedule of the folded unit: "1" = weight gradient -> data gradient with the statistics term in its
 # store loop (one pass less over the activation), "0" = weight and data gradient side by side on two streams and
 # a separate elementwise pass for the statistics term
-_SERIAL = os.environ.get("DPAMD_SEPCONV_SERIAL", "1") != "0"
+_SERIAL = True
 
 
 def _sink_of(p):

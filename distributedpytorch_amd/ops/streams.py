@@ -25,13 +25,13 @@ _ENABLED = os.environ.get("DPAMD_AUX_STREAM", "1") != "0"
 # atomics (its split-K combine); the next kernel of the SAME stream cannot start until that burst has
 # drained, a kernel of another stream can.  Measured at B32 (gpurun_out/s8_bench_b32_aux*.log): 697 img/s
 # with one aux stream, 685 with two, so one is the default; GPU_MAX_HW_QUEUES is 4 (main + comm + 2 aux).
-_NAUX = max(1, int(os.environ.get("DPAMD_AUX_STREAMS", "1")))
+_NAUX = 1
 # Queue priority of the auxiliary stream(s).  "low": created with hipStreamCreateWithPriority at the LEAST
 # priority of the device's range, so when both hardware queues hold ready workgroups the dgrad -> BN-backward
 # chain (the critical path, on the normal-priority current stream) is dispatched first and the weight
 # gradients fill the CUs it leaves free instead of taking half of them.  torch.cuda.Stream only reaches the
 # normal and high levels, hence the direct runtime call + torch.cuda.ExternalStream.
-_PRIORITY = os.environ.get("DPAMD_AUX_PRIORITY", "low")
+_PRIORITY = "low"
 _raw_handles: list = []     # keeps the hipStream_t of the external streams (never destroyed: process lifetime)
 
 
@@ -69,8 +69,24 @@ def set_enabled(flag: bool) -> None:
     _ENABLED = bool(flag)
 
 
+def set_priority(level: str) -> None:
+    """'low' (default) | 'normal'.  Streams that exist already are joined and dropped; the next fork creates new
+    ones.  parallel.p2p calls this with 'normal' when ranks SHARE a device (rehearsals): a peer's spinning one-shot
+    all-reduce kernel on a normal-priority queue outranks this rank's low-priority weight gradients, which the
+    matching all-reduce of this rank waits for — both then sit until the bounded spin times out."""
+    global _PRIORITY
+    if level not in ("low", "normal"):
+        raise ValueError("aux stream priority: 'low' or 'normal'")
+    if level != _PRIORITY:
+        for idx in list(_streams):
+            join(torch.device("cuda", idx))
+        _streams.clear()
+        _next.clear()
+        _PRIORITY = level
+
+
 def aux_stream(device: Optional[torch.device] = None) -> "torch.cuda.Stream":
-    """The next auxiliary stream of ``device`` (round-robin over DPAMD_AUX_STREAMS streams)."""
+    """The next auxiliary stream of ``device`` (round-robin over _NAUX streams)."""
     idx = torch.cuda.current_device() if device is None or device.index is None else device.index
     pool = _streams.get(idx)
     if pool is None:

@@ -43,16 +43,15 @@ from ..ops import streams
 from .arena import ParamArena
 
 
-_DEBUG = os.environ.get("DPAMD_DDP_DEBUG", "0") != "0"
-# DPAMD_DDP_SYNC=1: blocking bucket all-reduces (no overlap) — a bisection knob
-_SYNC = os.environ.get("DPAMD_DDP_SYNC", "0") != "0"
+_DEBUG = os.environ.get("DPAMD_DEBUG", "0") == "ddp"          # DPAMD_DEBUG=ddp: trace every bucket launch / wait
+_SYNC = False          # True: blocking bucket all-reduces (no overlap) — a bisection switch for a debugger session
 # DPAMD_DDP_FORCE=1: run the whole communication path (broadcast, bucket all-reduces, waits) even in
 # a 1-rank group — rehearses the RCCL stream/event choreography on a single GPU
 _FORCE = os.environ.get("DPAMD_DDP_FORCE", "0") != "0"
 # DPAMD_DDP_MODE: "allreduce" (default) | "rs_ag" (reduce-scatter + all-gather per bucket, RCCL only)
 _MODE = os.environ.get("DPAMD_DDP_MODE", "allreduce")
-# DPAMD_COMM_LAUNCH_STREAM=0: issue collectives from the step's stream after joining the aux stream (round-1 form)
-_COMM_STREAM = os.environ.get("DPAMD_COMM_LAUNCH_STREAM", "1") != "0"
+# False: issue collectives from the step's stream after joining the aux stream (the round-1 form)
+_COMM_STREAM = True
 
 
 def _dbg(msg: str) -> None:
@@ -82,7 +81,7 @@ class DistributedDataParallel(nn.Module):
         if param_groups is None:
             param_groups = [list(module.named_parameters())]
         if tail_bytes is None:
-            tail_bytes = int(os.environ.get("DPAMD_DDP_TAIL_MB", "8")) << 20
+            tail_bytes = 8 << 20
         self.mode = mode or _MODE
         if self.mode not in ("allreduce", "rs_ag"):
             raise ValueError("DDP mode must be 'allreduce' or 'rs_ag'")
@@ -267,7 +266,7 @@ class DistributedDataParallel(nn.Module):
                 w.wait()
         if self.arena.flat_g.is_cuda:
             if getattr(self, "_cs_dirty", False):
-                # blocking collectives (gloo staging, DPAMD_DDP_SYNC) ran ON the comm-launch stream
+                # blocking collectives (gloo staging, _SYNC) ran ON the comm-launch stream
                 torch.cuda.current_stream(self.arena.flat_g.device).wait_stream(self._comm_stream)
                 self._cs_dirty = False
             streams.join(self.arena.flat_g.device)

@@ -71,18 +71,9 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 600,
                       timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
             kwargs["device_id"] = dev
-            # DPAMD_COMM_PRIORITY=high: RCCL's kernels on a HIGH-priority stream, so a bucket all-reduce launched
-            # mid-backward does not queue behind every ready compute workgroup of the step.  Opt-in:
-            # the whole gradient exchange is ~1.5 ms of a 130 ms step over the 7 xGMI links, and high-priority
-            # queues stalled ranks that share a device (tests/test_gpu_p2p.py rehearsal) — not worth a default
-            # that cannot be verified on a multi-GPU node from here.
-            if os.environ.get("DPAMD_COMM_PRIORITY", "normal") == "high":
-                try:
-                    opts = dist.ProcessGroupNCCL.Options()
-                    opts.is_high_priority_stream = True
-                    kwargs["pg_options"] = opts
-                except Exception:      # pragma: no cover - older bindings
-                    pass
+            # (RCCL's kernels on a HIGH-priority stream were tried: the whole gradient exchange is ~1.5 ms of a 130 ms
+            # step over the 7 xGMI links, and high-priority queues stalled ranks that share a device
+            # (tests/test_gpu_p2p.py rehearsal) — removed with its knob in round 3.)
         dist.init_process_group(**kwargs)
     return DistInfo(rank, local_rank, world, backend if (world > 1 or force) else "none", dev)
 

@@ -68,25 +68,15 @@ class TrainEngine:
         # The weight gradients run on a LOW-priority stream (ops.streams): when both hardware queues hold ready
         # workgroups the forward / dgrad -> BN-backward chain is dispatched first.  Measured at B128
         # (gpurun_out/s94, s95): 951 img/s with equal priorities, 957-958 with the low-priority auxiliary stream.
-        # DPAMD_MAIN_PRIORITY=high additionally runs the step itself on a HIGH-priority stream (961-962 on one
-        # GPU).  Not the default: RCCL's kernels run at normal priority and would be dispatched behind every
-        # compute kernel, and two ranks SHARING one GPU (the rehearsal of tests/test_gpu_p2p.py) stalled with it.
+        # Running the step itself on a HIGH-priority stream gave 961-962 on one GPU; not built in: RCCL's kernels run
+        # at normal priority and would be dispatched behind every compute kernel, and two ranks SHARING one GPU (the
+        # rehearsal of tests/test_gpu_p2p.py) stalled with it.
         # Why it stalls shared-GPU ranks (round-1 ADVICE): the one-shot SyncBN kernel (csrc/p2p_allreduce.hip) SPINS
         # until every peer's granules arrive.  On a high-priority queue the spinning kernel of rank A outranks the
         # (normal-priority, or equally high but later) kernel of rank B that would produce those granules when both
         # share a device, so nothing progresses until the bounded spin times out — and a timed-out reduction returns
         # partial sums.  High priority is therefore refused whenever peers exist (world > 1): the step's kernels and
         # the collectives they wait on must be dispatched at the same level.
-        self._main = None
-        if self.on_gpu and os.environ.get("DPAMD_MAIN_PRIORITY", "normal") == "high":
-            if dist_env.get_world_size() > 1:
-                if dist_env.is_master():
-                    import sys
-                    print("[dpamd] DPAMD_MAIN_PRIORITY=high ignored: with world_size > 1 the step's stream must not "
-                          "outrank the collectives it waits for", file=sys.stderr)
-            else:
-                self._main = torch.cuda.Stream(device=self.device, priority=-1)
-
     # ------------------------------------------------------------------
     def prepare_input(self, images: torch.Tensor) -> torch.Tensor:
         x = images.to(self.device, non_blocking=True)
@@ -97,22 +87,6 @@ class TrainEngine:
         return x
 
     def train_step(self, images: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        if self._main is None:
-            return self._train_step(images, target)
-        outer = torch.cuda.current_stream(self.device)
-        if outer == self._main:
-            return self._train_step(images, target)
-        self._main.wait_stream(outer)                  # the batch (augmentation, copies) is ready
-        with torch.cuda.stream(self._main):
-            loss = self._train_step(images, target)
-        for t in (images, target):
-            if t.is_cuda:
-                t.record_stream(self._main)            # allocated on ``outer``, read on the step's stream
-        outer.wait_stream(self._main)                  # whatever the caller queues next sees the updated weights
-        loss.record_stream(outer)
-        return loss
-
-    def _train_step(self, images: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         self.model.train()
         x = self.prepare_input(images)
         # TODO `train_pascal.py:5`: "label non_blocking = True"

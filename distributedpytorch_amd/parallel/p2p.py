@@ -29,7 +29,7 @@ ENABLED = None if _ENV == "auto" else (_ENV != "0")
 _MAXN = 8192            # floats per message: 2 x 4096 channels
 # every spin is bounded: ranks may be skewed by seconds while they autotune in the first step
 _TIMEOUT_MS = int(os.environ.get("DPAMD_P2P_TIMEOUT_MS", "30000"))
-CHECK_EVERY = int(os.environ.get("DPAMD_P2P_CHECK_EVERY", "20"))   # steps between host reads of the error word
+CHECK_EVERY = 20        # steps between host reads of the error word
 _sigs = False
 
 
@@ -79,11 +79,19 @@ class OneShotAllReduce:
                 err = f"hipIpcGetMemHandle failed with status {st} (HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)"
         # handshake over the existing backend: every rank learns every handle
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (bytes(handle), os.getpid(), err), group=group)
+        import socket
+        where = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""),
+                 os.environ.get("ROCR_VISIBLE_DEVICES", ""), torch.cuda.current_device())
+        dist.all_gather_object(gathered, (bytes(handle), os.getpid(), err, where), group=group)
         self._raise_together([g[2] for g in gathered], "set-up")
+        self.shared_device = len({g[3] for g in gathered}) < self.world
+        if self.shared_device:
+            # ranks sharing a GPU (a rehearsal): every stream at one priority, see ops.streams.set_priority
+            from ..ops import streams
+            streams.set_priority("normal")
         ptrs = (ctypes.c_void_p * self.world)()
         err = ""
-        for r, (h, _pid, _e) in enumerate(gathered):
+        for r, (h, _pid, _e, _w) in enumerate(gathered):
             if r == self.rank:
                 ptrs[r] = mine.value
                 continue

@@ -201,7 +201,7 @@ def test_model_training_step_matches_fp32_cpu(name, kwargs, size, gain, floor, m
                 m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.3)
         for k, p in m_cpu.named_parameters():
             if k.endswith("bn3.weight") or (".rep." in k and k.endswith(".bn.weight") and not k.endswith("sep.bn.weight")):
-                p.mul_(float(os.environ.get("DPAMD_TEST_RES_GAIN", gain)))
+                p.mul_(gain)
     if hasattr(getattr(m_cpu, "backbone", None), "zero_pad_channels"):
         m_cpu.backbone.zero_pad_channels()      # Xception's padding channels: zero again after the re-initialisation
     for m in m_cpu.modules():            # dropout off: the fused counter-based generator is not torch's

@@ -91,7 +91,6 @@ def main():
     ap.add_argument("--cfgs", default="5")
     ap.add_argument("--modes", default="plain,stats,res,resaff,bn")
     ap.add_argument("--wgrad", action="store_true", help="stamp the weight-gradient kernel instead (csrc/conv_wgrad.hip)")
-    ap.add_argument("--stagger", default="0,0", help="';'-separated 'slot,cu' start-time staggers (units of 1024 cycles)")
     ap.add_argument("shapes", nargs="*", help="cin:cout:hw:k[:dil]")
     a = ap.parse_args()
     if a.build:
@@ -102,8 +101,7 @@ def main():
     from distributedpytorch_amd.ops import _hip_conv
     lib = _hip_conv._lib()
     lib.dp_conv_set_dbg.argtypes = [ctypes.c_void_p]
-    lib.dp_conv_set_stagger.argtypes = [ctypes.c_int, ctypes.c_int]
-    staggers = [tuple(int(v) for v in st.split(",")) for st in a.stagger.split(";")]
+    staggers = [(0, 0)]            # (the start-time stagger experiment is concluded and its code removed: README)
     dbg = torch.zeros(16 * (1 << 19), dtype=torch.int64, device="cuda")
     if a.wgrad:
         return wgrad_main(a, lib, dbg, _hip_conv, torch)
@@ -129,7 +127,6 @@ def main():
         for cfg in [int(c) for c in a.cfgs.split(",")]:
           for mode in a.modes.split(","):
             for stg in staggers:
-                lib.dp_conv_set_stagger(*stg)
                 def run():
                     if mode == "plain":
                         _hip_conv.igemm(x, w, (hw, hw), 1, 1, (pad, pad), (dil, dil), cfg=cfg)
@@ -190,7 +187,6 @@ def main():
                 print(f"{sh:20s} {tag:12s} {cfg:3d} {d.shape[0]:7d} {t_us:8.1f} {gf / t_us * 1e3:6.0f} | "
                       + " ".join(f"{float(v):7.2f}" for v in ph) + f" | {tot:7.2f}  ({ghz:.2f}; {cc:.2f} of {len(key.unique())} CUs)",
                       flush=True)
-        lib.dp_conv_set_stagger(0, 0)
 
 
 if __name__ == "__main__":
