@@ -383,3 +383,107 @@ DP_EXPORT int dp_nellipse_guidance(const int* pts, void* red, void* out, int B, 
                        alpha, inv_sigma2, mean, 1.f / stdv);
     return DP_LAUNCH_STATUS();
 }
+
+// ---- validation of the instance task on the device (train_pascal.py:280-306 of the reference) -------------------
+// Per object the reference pastes the crop-sized sigmoid back into a full-size canvas (helpers.crop2fullmask:
+// bicubic resize of the crop to the bounding box, the `relax` border suppressed), thresholds it and takes the
+// Jaccard index against the full-size mask with void pixels excluded — on the host, one object at a time, after a
+// device->host copy of every prediction.  Here one kernel walks the full-size pixels of every object of the batch,
+// samples the crop prediction where the canvas would hold it and counts intersection / union for all thresholds.
+// Counts are integers (atomics: order-independent), one host read per epoch.
+namespace {
+
+struct PasteJac {
+    const void* logits;            // [B, Hc, Wc] fp32 or bf16 (is_bf16)
+    const unsigned char* gt;       // [slots, Hi, Wi] object mask (!= 0)
+    const unsigned char* vd;       // [slots, Hi, Wi] void mask (!= 0) or null
+    const int* src_idx;            // [B] slot of sample b, or null (slot = b)
+    const int* sizes;              // [B, 2] (h, w) of the image inside its slot
+    const int* bbox;               // [B, 4] inclusive crop box on the image (may reach outside it; x1 < x0: no object)
+    int* counts;                   // [B, T, 2] (intersection, union)
+    float th[4];
+    int B, Hi, Wi, Hc, Wc, relax, T, is_bf16;
+};
+
+__global__ __launch_bounds__(256) void paste_jaccard_kernel(PasteJac p) {
+    const int b = blockIdx.y;
+    const int slot = p.src_idx ? p.src_idx[b] : b;
+    const int H = p.sizes[2 * b], W = p.sizes[2 * b + 1];
+    const int x0 = p.bbox[4 * b], y0 = p.bbox[4 * b + 1], x1 = p.bbox[4 * b + 2], y1 = p.bbox[4 * b + 3];
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    const bool has_box = bw > 0 && bh > 0;
+    const unsigned char* gt = p.gt + (size_t)slot * p.Hi * p.Wi;
+    const unsigned char* vd = p.vd ? p.vd + (size_t)slot * p.Hi * p.Wi : nullptr;
+    const size_t lbase = (size_t)b * p.Hc * p.Wc;
+    int inter[4] = {0, 0, 0, 0}, uni[4] = {0, 0, 0, 0};
+    const long npx = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        if (vd && vd[(size_t)y * p.Wi + x]) continue;
+        const bool g = gt[(size_t)y * p.Wi + x] != 0;
+        float val = 0.f;
+        const int cx = x - x0, cy = y - y0;
+        if (has_box && cx >= p.relax && cx < bw - p.relax && cy >= p.relax && cy < bh - p.relax) {
+            // imgproc.resize(crop, (bh, bw), INTER_CUBIC): half-pixel centres, taps clamped to the edge
+            const double sx = ((double)cx + 0.5) * ((double)p.Wc / bw) - 0.5, sy = ((double)cy + 0.5) * ((double)p.Hc / bh) - 0.5;
+            const double fx = floor(sx), fy = floor(sy);
+            const float ax = (float)(sx - fx), ay = (float)(sy - fy);
+            const int ix = (int)fx, iy = (int)fy;
+#pragma unroll
+            for (int oy = -1; oy <= 2; ++oy) {
+                const float wy = cubic_w(ay - (float)oy);
+                const int yy = min(max(iy + oy, 0), p.Hc - 1);
+#pragma unroll
+                for (int ox = -1; ox <= 2; ++ox) {
+                    const int xx = min(max(ix + ox, 0), p.Wc - 1);
+                    const size_t off = lbase + (size_t)yy * p.Wc + xx;
+                    const float z = p.is_bf16 ? bf2f(reinterpret_cast<const bf16_raw*>(p.logits)[off])
+                                              : reinterpret_cast<const float*>(p.logits)[off];
+                    val = fmaf(cubic_w(ax - (float)ox) * wy, 1.f / (1.f + __expf(-z)), val);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < p.T) {
+                const bool pr = val > p.th[t];
+                inter[t] += (pr && g) ? 1 : 0;
+                uni[t] += (pr || g) ? 1 : 0;
+            }
+        }
+    }
+    __shared__ int part[4][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int a = inter[t], u = uni[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); u += __shfl_xor(u, o, 64); }
+        if (lane == 0) { part[wave][2 * t] = a; part[wave][2 * t + 1] = u; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * p.T) {
+        const int v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (v) atomicAdd(p.counts + (size_t)b * p.T * 2 + threadIdx.x, v);
+    }
+}
+
+}  // namespace
+
+// counts: int32 [B, T, 2], zero-initialised (or holding counts to add to).  T <= 4 thresholds.
+DP_EXPORT int dp_paste_jaccard(const void* logits, int is_bf16, const void* gt, const void* vd, const int* src_idx,
+                               const int* sizes, const int* bbox, int* counts, const float* th, int T, int B, int Hi,
+                               int Wi, int Hc, int Wc, int relax, hipStream_t st) {
+    if (!logits || !gt || !sizes || !bbox || !counts || !th || T < 1 || T > 4 || B <= 0 || Hi <= 0 || Wi <= 0 || Hc <= 0 ||
+        Wc <= 0 || relax < 0)
+        return -1;
+    PasteJac p{};
+    p.logits = logits; p.gt = (const unsigned char*)gt; p.vd = (const unsigned char*)vd; p.src_idx = src_idx;
+    p.sizes = sizes; p.bbox = bbox; p.counts = counts;
+    for (int t = 0; t < T; ++t) p.th[t] = th[t];
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Hc = Hc; p.Wc = Wc; p.relax = relax; p.T = T; p.is_bf16 = is_bf16;
+    int gx = (int)(((long)Hi * Wi + 255) / 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(paste_jaccard_kernel, dim3(gx, B), dim3(256), 0, st, p);
+    return DP_LAUNCH_STATUS();
+}

@@ -89,17 +89,20 @@ class DeviceSampleStore:
     """The decoded dataset, resident on the device: ``images`` uint8 [N,Hs,Ws,3], ``labels`` uint8 [N,Hs,Ws],
     ``sizes`` int32 [N,2]."""
 
-    def __init__(self, n: int, slot: Tuple[int, int], device: torch.device, label_fill: int = 255):
+    def __init__(self, n: int, slot: Tuple[int, int], device: torch.device, label_fill: int = 255,
+                 keep_void: bool = False):
         self.n, self.slot, self.device = n, tuple(slot), device
         self.images = torch.empty(n, slot[0], slot[1], 3, dtype=torch.uint8, device=device)
         self.labels = torch.full((n, slot[0], slot[1]), label_fill, dtype=torch.uint8, device=device)
+        # void masks (instance validation: pixels excluded from the Jaccard index, train_pascal.py:291)
+        self.voids = torch.zeros(n, slot[0], slot[1], dtype=torch.uint8, device=device) if keep_void else None
         self.sizes = torch.ones(n, 2, dtype=torch.int32, device=device)
         self.sizes_host = np.ones((n, 2), dtype=np.int32)
         self.filled = np.zeros(n, dtype=bool)
 
     @property
     def nbytes(self) -> int:
-        return self.images.numel() + self.labels.numel()
+        return self.images.numel() + self.labels.numel() + (self.voids.numel() if self.voids is not None else 0)
 
     @staticmethod
     def bytes_needed(n: int, slot: Tuple[int, int]) -> int:
@@ -118,10 +121,14 @@ class DeviceSampleStore:
                     di = idx.to(self.device, non_blocking=True)
                     self.images.index_copy_(0, di, b["image"].to(self.device, non_blocking=True))
                     self.labels.index_copy_(0, di, b["label"].to(self.device, non_blocking=True))
+                    if self.voids is not None and "void" in b:
+                        self.voids.index_copy_(0, di, b["void"].to(self.device, non_blocking=True))
                     self.sizes.index_copy_(0, di, b["sizes"].to(self.device, non_blocking=True))
                 side.synchronize()          # the pinned batch is recycled by the loader after this iteration
             else:
                 self.images[idx], self.labels[idx], self.sizes[idx] = b["image"], b["label"], b["sizes"]
+                if self.voids is not None and "void" in b:
+                    self.voids[idx] = b["void"]
             self.sizes_host[idx.numpy()] = b["sizes"].numpy()
             self.filled[idx.numpy()] = True
             if progress is not None:
@@ -149,11 +156,14 @@ class GpuBatchLoader:
     def __init__(self, base: Dataset, sampler, batch: int, device: torch.device, crop: int, task: str = "semseg",
                  scales=(0.5, 2.0), rots=(0.0, 0.0), flip_p: float = 0.5, seed: int = 0, rank: int = 0,
                  workers: int = 4, mode: str = "auto", hbm_budget_gb: float = 64.0, train: bool = True,
-                 out_dtype: Optional[torch.dtype] = None, relax: int = 50, zero_pad: bool = True):
+                 out_dtype: Optional[torch.dtype] = None, relax: int = 50, zero_pad: bool = True,
+                 drop_last: Optional[bool] = None):
         self.raw = RawUint8(base, task)
         self.sampler, self.batch, self.device, self.crop, self.task = sampler, int(batch), device, int(crop), task
         self.scales, self.rots, self.flip_p, self.train = scales, rots, flip_p, train
         self.relax, self.zero_pad = relax, zero_pad
+        self.drop_last = train if drop_last is None else bool(drop_last)     # validation visits the tail batch too
+        self.with_meta = False               # iter_eval(): batches come with what the device metric needs
         self.workers = workers
         self.out_dtype = out_dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32)
         self.rng = np.random.default_rng([seed, rank, 0x9E37])       # rank-dependent augmentation stream
@@ -168,7 +178,8 @@ class GpuBatchLoader:
         self.steps = 0
 
     def __len__(self) -> int:
-        return len(self.sampler) // self.batch
+        n = len(self.sampler)
+        return n // self.batch if self.drop_last else (n + self.batch - 1) // self.batch
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -200,11 +211,22 @@ class GpuBatchLoader:
 
     def prepare(self, progress=None) -> None:
         if self.mode == "cache" and self.store is None:
-            self.store = DeviceSampleStore(len(self.raw), self.slot, self.device, self.label_fill)
+            self.store = DeviceSampleStore(len(self.raw), self.slot, self.device, self.label_fill,
+                                           keep_void=self.task == "instance" and not self.train)
             self.store.fill(self.raw, self.workers, label_fill=self.label_fill, progress=progress)
 
     # ------------------------------------------------------------------
-    def _augment(self, images, labels, src_idx, sizes_dev, sizes_host, idx_host=None):
+    def iter_eval(self):
+        """Validation batches ``(x, y, meta)``: ``meta`` = what ``ops.augment.paste_jaccard`` needs to score the
+        predictions on the device — the full-size masks (``gt``, ``void``: the store's tensors or the uploaded
+        batch), ``src_idx`` into them, ``sizes`` and, for the instance task, the ``crop_bbox`` of every object."""
+        self.with_meta = True
+        try:
+            yield from iter(self)
+        finally:
+            self.with_meta = False
+
+    def _augment(self, images, labels, src_idx, sizes_dev, sizes_host, idx_host=None, voids=None):
         bsz = len(sizes_host)
         # validate the HOST copies; the device path then launches without reading anything back (no host sync)
         ops.augment.check_slots(idx_host, sizes_host, images.shape[0], images.shape[1:3])
@@ -222,15 +244,19 @@ class GpuBatchLoader:
             # a few hundred bytes from pageable memory: the runtime stages such copies itself; pinning a fresh buffer
             # per step costs a host allocation of milliseconds (measured as 12 ms of data wait per step)
             m = torch.from_numpy(mats).to(self.device, non_blocking=True)
-            return ops.affine_augment2(images, labels, m, out, src_idx, sizes_dev, out_dtype=self.out_dtype,
+            x, y = ops.affine_augment2(images, labels, m, out, src_idx, sizes_dev, out_dtype=self.out_dtype,
                                        validated=True)
+            return (x, y, {"gt": labels, "void": None, "src_idx": src_idx, "sizes": sizes_dev}) if self.with_meta \
+                else (x, y)
         warp = ops.make_warp_params(bsz, sizes_host, self.rots, self.scales, self.flip_p if self.train else 0.0,
                                     self.rng) if self.train else \
             np.tile(np.array([1, 0, 0, 0, 1, 0], dtype=np.float32), (bsz, 1))
         w = torch.from_numpy(np.ascontiguousarray(warp, dtype=np.float32)).to(self.device, non_blocking=True)
-        x, y, _ = ops.instance_augment(images, labels, src_idx, sizes_dev, w, out, self.relax, self.zero_pad,
-                                       random_points=self.train, seed=int(self.rng.integers(0, 2 ** 31 - 1)),
-                                       out_dtype=self.out_dtype, validated=True)
+        seed = int(self.rng.integers(0, 2 ** 31 - 1)) if self.train else 0     # validation draws nothing
+        x, y, bbox = ops.instance_augment(images, labels, src_idx, sizes_dev, w, out, self.relax, self.zero_pad,
+                                          random_points=self.train, seed=seed, out_dtype=self.out_dtype, validated=True)
+        if self.with_meta:
+            return x, y, {"gt": labels, "void": voids, "src_idx": src_idx, "sizes": sizes_dev, "crop_bbox": bbox}
         return x, y
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
@@ -243,17 +269,17 @@ class GpuBatchLoader:
         self.prepare()
         st = self.store
         order = np.fromiter(iter(self.sampler), dtype=np.int64)
-        for k in range(len(order) // self.batch):
+        for k in range(len(self)):
             idx = order[k * self.batch:(k + 1) * self.batch]
             src = torch.from_numpy(idx.astype(np.int32)).to(self.device, non_blocking=True)
             sizes_host = st.sizes_host[idx]
             sizes_dev = st.sizes.index_select(0, src.long()) if self.device.type == "cuda" else st.sizes[idx]
-            yield self._augment(st.images, st.labels, src, sizes_dev, sizes_host, idx)
+            yield self._augment(st.images, st.labels, src, sizes_dev, sizes_host, idx, st.voids)
 
     def _iter_stream(self):
         on_gpu = self.device.type == "cuda"
         loader = DataLoader(self.raw, batch_size=self.batch, sampler=self.sampler, num_workers=self.workers,
-                            drop_last=True, pin_memory=on_gpu, persistent_workers=False,
+                            drop_last=self.drop_last, pin_memory=on_gpu, persistent_workers=False,
                             collate_fn=lambda ss: pad_collate(ss, None, self.label_fill))
         side = torch.cuda.Stream(device=self.device) if on_gpu else None
 
@@ -284,4 +310,4 @@ class GpuBatchLoader:
                     if torch.is_tensor(v):
                         v.record_stream(torch.cuda.current_stream(self.device))
             sizes_host = cur.pop("_sizes_host") if on_gpu else cur["sizes"].numpy()
-            yield self._augment(cur["image"], cur["label"], None, cur["sizes"], sizes_host)
+            yield self._augment(cur["image"], cur["label"], None, cur["sizes"], sizes_host, None, cur.get("void"))

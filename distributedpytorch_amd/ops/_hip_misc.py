@@ -37,6 +37,7 @@ def _lib():
         lib.dp_stem_pack.argtypes = [V, V, L, I, I, I, I, V]
         lib.dp_affine_augment2.argtypes = [V, V, V, V, V, V, V, V] + [I] * 9 + [V, V, V, V]
         lib.dp_mask_bbox.argtypes = [V, V, V, V, V, I, I, I, V]
+        lib.dp_paste_jaccard.argtypes = [V, I, V, V, V, V, V, V, V] + [I] * 7 + [V]
         lib.dp_compose_crop.argtypes = [V, V, V, V, V, V] + [I] * 7 + [V]
         lib.dp_extreme_points.argtypes = [V, V, V, I, I, I, I, c_int, V]
         lib.dp_nellipse_guidance.argtypes = [V, V, V, I, I, I, I, I, F, F, F, F, V]
@@ -332,6 +333,42 @@ def mask_bbox(mask_u8, src_idx, sizes, mats, validated=False):
     B.check(_lib().dp_mask_bbox(B.ptr(mask_u8), B.ptr(src_idx), B.ptr(sizes), B.ptr(mats), B.ptr(bbox), bsz, hi, wi,
                                 B.stream_ptr()), "mask_bbox")
     return bbox
+
+
+def paste_jaccard(logits, crop_bbox, gt_u8, void_u8, src_idx, sizes, relax, thresholds, counts=None, validated=False):
+    """int32 [B, T, 2] (intersection, union) — see ops.augment.paste_jaccard."""
+    import ctypes
+    bsz, hc, wc = logits.shape[0], logits.shape[-2], logits.shape[-1]
+    if logits.numel() != bsz * hc * wc or not logits.is_contiguous() or logits.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("paste_jaccard: contiguous fp32 / bf16 logits [B,1,Hc,Wc]")
+    if gt_u8.dtype != torch.uint8 or gt_u8.dim() != 3 or not gt_u8.is_contiguous():
+        raise ValueError("paste_jaccard: contiguous uint8 masks [N,H,W]")
+    if void_u8 is not None and (void_u8.dtype != torch.uint8 or void_u8.shape != gt_u8.shape or not void_u8.is_contiguous()):
+        raise ValueError("paste_jaccard: void mask must match the object masks")
+    nslots, hi, wi = gt_u8.shape
+    dev = logits.device
+    src_idx = _i32(src_idx, (bsz,), "src_idx", dev)
+    sizes = _i32(sizes, (bsz, 2), "sizes", dev)
+    bbox = _i32(crop_bbox, (bsz, 4), "crop_bbox", dev)
+    if src_idx is None and bsz != nslots:
+        raise ValueError("without src_idx the store must hold exactly the batch")
+    if not validated:
+        if src_idx is not None and (int(src_idx.min()) < 0 or int(src_idx.max()) >= nslots):
+            raise IndexError("src_idx outside the store")
+        if int(sizes.min()) < 1 or int(sizes[:, 0].max()) > hi or int(sizes[:, 1].max()) > wi:
+            raise ValueError("sizes outside the slot dimensions")
+    nt = len(thresholds)
+    if not 1 <= nt <= 4:
+        raise ValueError("paste_jaccard: 1..4 thresholds")
+    if counts is None:
+        counts = torch.zeros((bsz, nt, 2), dtype=torch.int32, device=dev)
+    elif counts.dtype != torch.int32 or tuple(counts.shape) != (bsz, nt, 2) or not counts.is_contiguous():
+        raise ValueError("paste_jaccard: counts must be contiguous int32 [B, T, 2]")
+    th = (ctypes.c_float * nt)(*[float(t) for t in thresholds])
+    B.check(_lib().dp_paste_jaccard(B.ptr(logits), int(logits.dtype == torch.bfloat16), B.ptr(gt_u8), B.ptr(void_u8),
+                                    B.ptr(src_idx), B.ptr(sizes), B.ptr(bbox), B.ptr(counts), th, nt, bsz, hi, wi, hc, wc,
+                                    int(relax), B.stream_ptr()), "paste_jaccard")
+    return counts
 
 
 def compose_crop(mats, bbox, sizes, slot_size, out_size, relax, zero_pad):

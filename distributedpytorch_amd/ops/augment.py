@@ -341,6 +341,39 @@ def nellipse_guidance_(out: torch.Tensor, pts: torch.Tensor, channel: int = 3, a
 
 
 @torch.no_grad()
+@torch.no_grad()
+def paste_jaccard(logits: torch.Tensor, crop_bbox: torch.Tensor, gt_u8: torch.Tensor, void_u8: Optional[torch.Tensor],
+                  src_idx, sizes, relax: int = 50, thresholds=(0.3, 0.5, 0.8), validated: bool = False) -> torch.Tensor:
+    """Validation metric of the instance task without leaving the device
+    (`/root/reference/train_pascal.py:280-306`): for every object of the batch the crop-sized ``sigmoid(logits)``
+    is pasted back into its full-size canvas (``helpers.crop2fullmask``: bicubic resize to ``crop_bbox``, ``relax``
+    border suppressed, parts outside the image dropped), thresholded, and compared with the full-size object mask
+    ``gt_u8[src_idx]`` where ``void_u8`` is 0.  Returns int32 ``[B, T, 2]``: intersection and union pixel counts;
+    ``helpers.calc_jaccard`` = inter / union (1 when union is 0).  ``logits``: [B,1,Hc,Wc]."""
+    if B.use_hip(logits):
+        from . import _hip_misc
+        lg = logits if logits.dtype in (torch.float32, torch.bfloat16) else logits.float()
+        return _hip_misc.paste_jaccard(lg.contiguous(), crop_bbox, gt_u8, void_u8, src_idx, sizes, relax, thresholds,
+                                       validated=validated)
+    import numpy as np
+    from ..data import helpers
+    bsz = logits.shape[0]
+    out = torch.zeros(bsz, len(thresholds), 2, dtype=torch.int32)
+    prob = torch.sigmoid(logits.float()).reshape(bsz, logits.shape[-2], logits.shape[-1]).cpu().numpy()
+    for b in range(bsz):
+        slot = int(src_idx[b]) if src_idx is not None else b
+        h, w = int(sizes[b][0]), int(sizes[b][1])
+        gt = gt_u8[slot, :h, :w].cpu().numpy() != 0
+        valid = np.ones_like(gt) if void_u8 is None else void_u8[slot, :h, :w].cpu().numpy() == 0
+        bb = [int(v) for v in crop_bbox[b]]
+        full = helpers.crop2fullmask(prob[b], bb, im_size=(h, w), relax=relax)
+        for t, th in enumerate(thresholds):
+            pr = full > th
+            out[b, t, 0] = int(((pr & gt) & valid).sum())
+            out[b, t, 1] = int(((pr | gt) & valid).sum())
+    return out
+
+
 def instance_augment(img_u8: torch.Tensor, gt_u8: torch.Tensor, src_idx: torch.Tensor, sizes: torch.Tensor,
                      warp_mats: torch.Tensor, out_size: Tuple[int, int] = (512, 512), relax: int = 50,
                      zero_pad: bool = True, alpha: float = 0.6, random_points: bool = True, seed: int = 0,

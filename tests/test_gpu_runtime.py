@@ -116,6 +116,39 @@ def test_instance_pipeline_kernels_match_reference():
             assert all(mk[q[1], q[0]] for q in p)
 
 
+def test_paste_jaccard_kernel_matches_the_host_formulation():
+    """csrc/augment.hip paste_jaccard_kernel against ops.paste_jaccard on CPU tensors (helpers.crop2fullmask +
+    calc_jaccard of the reference's validation loop, `/root/reference/train_pascal.py:280-306`): smooth random
+    logits, boxes that reach outside the image, void pixels, an empty box, slots picked through src_idx, fp32 / bf16."""
+    from distributedpytorch_amd.ops.augment import paste_jaccard
+    g = torch.Generator().manual_seed(2)
+    nslots, hs, ws, bsz, hc = 6, 90, 120, 5, 64
+    gt = (torch.rand(nslots, hs, ws, generator=g) > 0.6).to(torch.uint8)
+    void = (torch.rand(nslots, hs, ws, generator=g) > 0.9).to(torch.uint8)
+    # smooth logits: a coarse random field upsampled, so that thresholds cut contours and not salt and pepper
+    logits = torch.nn.functional.interpolate(torch.randn(bsz, 1, 8, 8, generator=g) * 3, size=(hc, hc), mode="bicubic")
+    src = torch.tensor([4, 0, 5, 2, 2], dtype=torch.int32)
+    sizes = torch.tensor([[90, 120], [70, 100], [90, 64], [33, 120], [90, 120]], dtype=torch.int32)
+    bbox = torch.tensor([[-20, -30, 100, 80], [10, 5, 80, 60], [0, 0, 63, 89], [0, 0, -1, -1], [30, 20, 150, 110]],
+                        dtype=torch.int32)
+    for relax in (0, 7):
+        ref = paste_jaccard(logits, bbox, gt, void, src, sizes, relax, (0.3, 0.5, 0.8))
+        for dt in (torch.float32, torch.bfloat16):
+            lg = logits.to(dt)
+            want = ref if dt == torch.float32 else paste_jaccard(lg.float(), bbox, gt, void, src, sizes, relax,
+                                                                 (0.3, 0.5, 0.8))
+            got = paste_jaccard(lg.cuda(), bbox.cuda(), gt.cuda(), void.cuda(), src.cuda(), sizes.cuda(), relax,
+                                (0.3, 0.5, 0.8)).cpu()
+            assert got.shape == want.shape == (bsz, 3, 2)
+            assert got[3].abs().sum() == 0 or int(want[3].abs().sum()) == int(got[3].abs().sum())
+            # a pixel whose interpolated probability sits within float rounding of a threshold may flip: a handful
+            diff = (got - want).abs()
+            assert int(diff.max()) <= 6 and float(diff.float().mean()) < 1.0, (relax, dt, got.tolist(), want.tolist())
+            assert int(want[:, :, 1].sum()) > 10000
+    no_void = paste_jaccard(logits.cuda(), bbox.cuda(), gt.cuda(), None, src.cuda(), sizes.cuda(), 0, (0.5,)).cpu()
+    assert (no_void[:, 0, 1] >= ref[:, 1, 1] - 6).all()
+
+
 def test_gpu_batch_loader_feeds_engine():
     """train_pascal's GPU data path: device sample store -> gather -> TrainEngine (both tasks)."""
     from distributedpytorch_amd.data import SyntheticVOC

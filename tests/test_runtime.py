@@ -387,3 +387,86 @@ def test_validation_figure_written(tmp_path):
              str(tmp_path), "--log-every", "0", "--max-iters", "1"])
     png = tmp_path / "run_0" / "figures" / "val_epoch-0.png"
     assert png.is_file() and png.stat().st_size > 2000
+
+
+# ------------------------------------------------------------------------------ validation on the device path
+def test_device_validation_matches_the_host_validation(tmp_path):
+    """validation ran on the host (CPU transforms in DataLoader workers, every prediction copied back,
+    per-object NumPy Jaccard).  The device path — GpuBatchLoader(train=False) + ops.paste_jaccard / the device
+    confusion matrix — must give the same numbers.  Here both run on CPU tensors (the torch formulation of every
+    device op); tests/test_gpu_runtime.py repeats the metric kernel against this formulation on the GPU."""
+    import copy
+    import types
+
+    import train_pascal as tp
+    from distributedpytorch_amd.data import SyntheticVOC
+    from distributedpytorch_amd.data.gpu_pipeline import GpuBatchLoader
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.parallel import DistributedSampler, TrainEngine
+    from distributedpytorch_amd.utils import SegmentationMultiLosses
+    from torch.utils.data import DataLoader
+    dev = torch.device("cpu")
+    # ---- instance task: per-object Jaccard at .3/.5/.8 ----
+    args = types.SimpleNamespace(task="instance", crop=96, zero_pad_crop=1, max_iters=0)
+    db = SyntheticVOC(6, (120, 150), tp.build_transforms(args, False), "instance", seed=3)
+    raw = copy.copy(db)
+    raw.transform = None
+
+    class FromGuidance(torch.nn.Module):
+        """A "network" with a graded, object-shaped prediction (an untrained one saturates on 0..255 inputs): the logit
+        is an affine function of the n-ellipse guidance channel mixed with the image, so the three thresholds cut
+        three different masks and every stage of the input chain matters."""
+
+        def __init__(self):
+            super().__init__()
+            self.k = torch.nn.Parameter(torch.tensor(1.0 / 30.0))
+
+        def forward(self, x):
+            x = x.float()
+            return (x[:, 3:4] - 110.0 + 0.1 * (x[:, 0:1] - 128.0)) * self.k
+
+    eng = TrainEngine(FromGuidance(), SegmentationMultiLosses(1), lr=0.0, device=dev)
+    sampler = DistributedSampler(len(db), shuffle=False, drop_last=False, pad=False)
+    host = tp.validate_instance(eng, DataLoader(db, batch_size=1, sampler=sampler), args)
+    ld = GpuBatchLoader(raw, sampler, 4, dev, 96, "instance", workers=0, train=False, relax=50, zero_pad=True)
+    assert len(ld) == 2                         # 6 objects in batches of 4: the tail batch is visited
+    device = tp.validate_instance_device(eng, ld, args)
+    assert device["img_per_s"] > 0
+    for a, b in zip(host["jaccard"], device["jaccard"]):
+        # the host chain resamples twice (crop, then resize), the device chain once: a few border pixels differ
+        assert abs(a - b) < 2e-3, (host, device)
+    assert 0.0 < max(device["jaccard"]) <= 1.0 and len({round(v, 3) for v in device["jaccard"]}) == 3
+    # ---- semantic task: mIoU from the device confusion matrix ----
+    from distributedpytorch_amd import ops
+    sargs = types.SimpleNamespace(task="semseg", crop=64, zero_pad_crop=1, max_iters=0)
+    sdb = SyntheticVOC(5, (80, 100), tp.build_transforms(sargs, False), "semantic", seed=4)
+    sraw = copy.copy(sdb)
+    sraw.transform = None
+    torch.manual_seed(1)
+    seng = TrainEngine(build_model("fcn_resnet18", 21), ops.SoftmaxCrossEntropy(255), lr=0.0, device=dev)
+    ssampler = DistributedSampler(len(sdb), shuffle=False, drop_last=False, pad=False)
+    h = seng.evaluate(tp._KeyLoader(DataLoader(sdb, batch_size=2, sampler=ssampler), "image", "gt"), 21, 255)
+    sld = GpuBatchLoader(sraw, ssampler, 2, dev, 64, "semseg", workers=0, train=False)
+    assert len(sld) == 3
+    d = seng.evaluate(tp._Ticked(sld), 21, 255)
+    assert abs(h["miou"] - d["miou"]) < 0.01 and abs(h["pixel_acc"] - d["pixel_acc"]) < 0.01, (h, d)
+
+
+def test_paste_jaccard_counts():
+    """ops.paste_jaccard on a hand-made case: a confident square prediction pasted back to a box that reaches outside
+    the image, void pixels excluded, an empty box."""
+    from distributedpytorch_amd.ops.augment import paste_jaccard
+    gt = torch.zeros(2, 40, 50, dtype=torch.uint8)
+    gt[0, 10:30, 15:35] = 1
+    void = torch.zeros_like(gt)
+    void[0, 10:12] = 1                                   # two object rows are void
+    logits = torch.full((2, 1, 32, 32), -9.0)
+    logits[0, 0, 8:24, 8:24] = 9.0                       # the centre quarter of the crop
+    bbox = torch.tensor([[5, 0, 44, 39], [0, 0, -1, -1]], dtype=torch.int32)      # 40 x 40 box; none
+    sizes = torch.tensor([[40, 50], [40, 50]], dtype=torch.int32)
+    c = paste_jaccard(logits, bbox, gt, void, None, sizes, relax=0, thresholds=(0.5,))
+    # crop quarter -> box pixels 10..29 in both directions -> image x 15..34, y 10..29: exactly the object
+    assert c[0, 0].tolist() == [18 * 20, 18 * 20] and c[1, 0].tolist() == [0, 0]
+    c = paste_jaccard(logits, bbox, gt, None, None, sizes, relax=12, thresholds=(0.5, 0.9))
+    # relax 12 keeps box pixels 12..27: 16 x 16 predicted, all inside the 20 x 20 object
+    assert c[0, 0].tolist() == [256, 400] and c[0, 1].tolist() == [256, 400]

@@ -99,6 +99,9 @@ def parse_args(argv=None):
     ap.add_argument("--data-path", choices=["auto", "gpu", "cpu"], default="auto",
                     help="gpu: decoded uint8 dataset resident in HBM + one augmentation gather per step "
                          "(data.gpu_pipeline); cpu: the reference's worker-side transforms (behaviour parity)")
+    ap.add_argument("--val-path", choices=["auto", "cpu"], default="auto",
+                    help="auto: validation follows --data-path (device store + device metric); cpu: the reference's host "
+                         "validation (DataLoader transforms, per-object NumPy Jaccard) even on the GPU data path")
     ap.add_argument("--gpu-cache-gb", type=float, default=64.0, help="HBM budget of the device sample store; larger "
                     "datasets stream raw uint8 batches one step ahead instead")
     ap.add_argument("--sbd-root", default=None, help="SBD benchmark_RELEASE root for --use_sbd 1")
@@ -335,6 +338,64 @@ def validate_instance(engine, loader, args, epoch=0, fig_path=None, tick=None):
     return {"jaccard": [t / cnt for t in tot[:3]], "loss": tot[3] / cnt}
 
 
+@torch.no_grad()
+def validate_instance_device(engine, loader, args, epoch=0, fig_path=None, tick=None):
+    """``validate_instance`` without leaving the device: the validation chain (mask bbox -> relax-50
+    crop -> resize -> fixed extreme points -> guidance -> concat) runs in ``GpuBatchLoader(train=False)``, the
+    predictions are pasted back, thresholded and scored by ``ops.paste_jaccard`` against the full-size masks in the
+    device store, and the host reads ONE vector per epoch (the CPU path copies every prediction to the host and
+    scores one object at a time in NumPy)."""
+    from distributedpytorch_amd.ops.augment import paste_jaccard
+    engine.model.eval()
+    thresh = (0.3, 0.5, 0.8)
+    dev = engine.device
+    acc = torch.zeros(5, dtype=torch.float64, device=dev)            # Σ jaccard (3 thresholds), Σ loss, #objects
+    t0, n_img = timeit.default_timer(), 0
+    for ii, (x, y, meta) in enumerate(loader.iter_eval()):
+        if args.max_iters and ii >= args.max_iters:
+            break
+        if tick is not None:
+            tick()
+        out = engine.model(engine.prepare_input(x))
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        bb = meta["crop_bbox"]
+        has = (bb[:, 2] >= bb[:, 0]).double()                        # an empty mask has no box: skipped, as on the host
+        cnt = paste_jaccard(outs[0], bb, meta["gt"], meta["void"], meta["src_idx"], meta["sizes"], 50, thresh,
+                            validated=True).double()
+        jac = torch.where(cnt[..., 1] > 0, cnt[..., 0] / cnt[..., 1].clamp_min(1.0), torch.ones_like(cnt[..., 0]))
+        acc[:3] += (jac * has[:, None]).sum(0)
+        acc[3] += engine.criterion(out, y).double() * x.shape[0]
+        acc[4] += has.sum()
+        n_img += x.shape[0]
+        if ii == 0 and fig_path is not None and dist_env.is_master():
+            from distributedpytorch_amd.utils.visualize import save_validation_panels
+            save_validation_panels(fig_path, x[0].float().cpu(), y[0, 0].float().cpu(),
+                                   [o[0].float().cpu() for o in outs], epoch)
+    if dist_env.get_world_size() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(acc)
+    tot = acc.tolist()                                               # the epoch's one host read
+    cnt = max(tot[4], 1.0)
+    dt = max(timeit.default_timer() - t0, 1e-9)
+    return {"jaccard": [t / cnt for t in tot[:3]], "loss": tot[3] / cnt,
+            "img_per_s": n_img * dist_env.get_world_size() / dt}
+
+
+class _Ticked:
+    """Device validation batches for ``TrainEngine.evaluate``: at most ``limit`` of them, the watchdog re-armed."""
+
+    def __init__(self, loader, limit=0, tick=None):
+        self.loader, self.limit, self.tick = loader, limit, tick
+
+    def __iter__(self):
+        for i, b in enumerate(self.loader):
+            if self.limit and i >= self.limit:
+                return
+            if self.tick is not None:
+                self.tick()
+            yield b
+
+
 class _KeyLoader:
     """Adapts dict batches to the (images, target) pairs ``TrainEngine.evaluate`` consumes."""
 
@@ -477,6 +538,15 @@ def main(argv=None):
     test_bs = args.testBatch if instance else max(args.testBatch, 1)
     testloader = DataLoader(db_val, batch_size=test_bs, sampler=val_sampler, num_workers=args.workers,
                             pin_memory=pin)
+    valloader = None
+    if data_path == "gpu" and args.val_path != "cpu":
+        # validation on the device too: the same samples (the sampler above), decoded once into a device store
+        import copy
+        db_val_raw = copy.copy(db_val)
+        db_val_raw.transform = None
+        valloader = GpuBatchLoader(db_val_raw, val_sampler, test_bs, info.device, args.crop, args.task, seed=args.seed,
+                                   rank=info.rank, workers=args.workers, hbm_budget_gb=args.gpu_cache_gb, train=False,
+                                   relax=50, zero_pad=bool(args.zero_pad_crop))
     scheduler = LR_Scheduler(args.lr_mode, args.lr, args.nEpochs, len(trainloader))
     # every rank continues ITS OWN augmentation stream (utils.checkpoint writes <ckpt>.state.rank<r> per rank)
     trainloader.load_state_dict(resumed_rank_state.get("loader", {}))
@@ -538,14 +608,27 @@ def main(argv=None):
         guard.progress()
         if args.useTest and epoch % args.nTestInterval == (args.nTestInterval - 1):
             fig = os.path.join(save_dir, "figures", "val_epoch-{}.png".format(epoch))
+            t_val = timeit.default_timer()
             if instance:
-                res = validate_instance(engine, testloader, args, epoch, fig, tick=guard.progress)
+                if valloader is not None:
+                    res = validate_instance_device(engine, valloader, args, epoch, fig, tick=guard.progress)
+                else:
+                    res = validate_instance(engine, testloader, args, epoch, fig, tick=guard.progress)
                 score = max(res["jaccard"])
-                log.log("val", epoch=epoch, loss=res["loss"], JACCARD=res["jaccard"])
+                log.log("val", epoch=epoch, loss=res["loss"], JACCARD=res["jaccard"],
+                        path="device" if valloader is not None else "host",
+                        img_per_s=res.get("img_per_s"), seconds=timeit.default_timer() - t_val)
             else:
-                res = engine.evaluate(_KeyLoader(testloader, kin, kgt, args.max_iters, tick=guard.progress), 21, 255)
+                if valloader is not None:
+                    res = engine.evaluate(_Ticked(valloader, args.max_iters, guard.progress), 21, 255)
+                else:
+                    res = engine.evaluate(_KeyLoader(testloader, kin, kgt, args.max_iters, tick=guard.progress), 21, 255)
                 score = res["miou"]
-                log.log("val", epoch=epoch, loss=res["loss"], mIoU=res["miou"], pixel_acc=res["pixel_acc"])
+                n_val = (min(args.max_iters, len(testloader)) if args.max_iters else len(testloader)) * test_bs
+                log.log("val", epoch=epoch, loss=res["loss"], mIoU=res["miou"], pixel_acc=res["pixel_acc"],
+                        path="device" if valloader is not None else "host",
+                        img_per_s=n_val * info.world_size / max(timeit.default_timer() - t_val, 1e-9),
+                        seconds=timeit.default_timer() - t_val)
                 if info.is_master:
                     _semseg_figure(engine, _KeyLoader(testloader, kin, kgt, 1), fig, epoch)
             if score > best_val:
