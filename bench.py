@@ -269,6 +269,10 @@ def main():
                      "exposed_comm_ms": round(comm_wait, 3)},
             "runtime": {"ops_backend": ops.get_backend()},
         }
+        if on_gpu:
+            rec["runtime"]["hbm_peak_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+        if args.impl == "stock" and os.environ.get("MIOPEN_FIND_MODE"):
+            rec["runtime"]["miopen_find_mode"] = os.environ["MIOPEN_FIND_MODE"]
         if comm_prof is not None:
             rec["comm"]["timeline_rank0"] = comm_prof
         mid = getattr(getattr(model, "backbone", None), "mid_physical", None)
@@ -299,6 +303,7 @@ def main():
                 record_self_baseline(args.model, S, B, {
                     "batch": B, "img_s": round(ips, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 2),
                     "steps": args.steps, "warmup": args.warmup, "source_log": args.source_log,
+                    "find_mode": os.environ.get("MIOPEN_FIND_MODE", "default (exhaustive search)"),
                     "note": "stock PyTorch-ROCm ops (MIOpen conv, ATen BN/CE, full-resolution logits + ATen "
                             "bilinear upsample), same model code, 1 x MI355X"})
         print(json.dumps(rec), flush=True)

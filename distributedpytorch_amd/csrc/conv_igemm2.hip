@@ -61,6 +61,8 @@ struct Conv2Args {
     const float* bn_w; const float* bn_b;         // [Cout] affine parameters or null (1, 0)
     float* bnsums;          // [bn_reps, 2, Cout]
     int bn_reps;
+    float mask_scale;       // dm = da·[a > 0]·mask_scale: 1, or 1/(1-p) when a dropout sits behind the ReLU (its zeros
+                            //   are in `a` already — the mask source — so only the scale of the kept elements is missing)
     int stat_reps;
     int M;
     int Hi, Wi, Cin, Ho, Wo, Cout, R, S;
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             bf16_raw* __restrict__ yout = p.y;
             const bool col_ok = gcol < p.Cout;
             const int gcl = col_ok ? gcol : 0;
+            const float msc = p.mask_scale;
             float mu[8], is[8], sc[8], sh[8], s1[8], s2[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -618,15 +621,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                     for (int j = 0; j < 8; ++j) a[j] += b[j];
                     if (bnm) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[j] = (vm[g] >> j) & 1u ? a[j] : 0.f;
+                        for (int j = 0; j < 8; ++j) a[j] = (vm[g] >> j) & 1u ? a[j] * msc : 0.f;
                     } else if (bna) {
                         float av[8];
                         unpack8(va[g], av);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[j] = av[j] > 0.f ? a[j] : 0.f;
+                        for (int j = 0; j < 8; ++j) a[j] = av[j] > 0.f ? a[j] * msc : 0.f;
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? a[j] : 0.f;
+                        for (int j = 0; j < 8; ++j) a[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? a[j] * msc : 0.f;
                     }
                     const uint4 o = pack8(a);
                     unpack8(o, a);        // reduce exactly what BN backward will read back (bf16-rounded)
@@ -734,6 +737,7 @@ thread_local const void* t_bnmask = nullptr;
 thread_local const float* t_bnp[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local float* t_bnsums = nullptr;
 thread_local int t_bn_reps = 0;
+thread_local float t_mask_scale = 1.f;
 thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
 thread_local const float* t_res_affine[2] = {nullptr, nullptr};   // set by dp_conv_igemm2ra
 thread_local int t_w_img = 0;    // set by dp_conv_igemm2pi
@@ -774,6 +778,7 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.bnmask = (const unsigned char*)t_bnmask;
     p.bn_mean = t_bnp[0]; p.bn_rstd = t_bnp[1]; p.bn_w = t_bnp[2]; p.bn_b = t_bnp[3];
     p.bn_reps = t_bn_reps < 1 ? 1 : t_bn_reps;
+    p.mask_scale = t_mask_scale;
     if (p.bnsums && (stats || ldy != Cout)) return -1;
     if (p.bnsums && !p.bnx && !p.bnmask && !p.bna) return -1;      // no pre-BN tensor: the mask needs a source
     p.stat_reps = stat_reps < 1 ? 1 : stat_reps;
@@ -820,16 +825,16 @@ DP_EXPORT int dp_conv_igemm2b(const void* x, const void* w, void* y, int N, int 
                               int Cout, int R, int S, int smul, int sdiv, int pad_h, int pad_w, int dil_h,
                               int dil_w, int cfg, const void* res, const void* bnx, const void* bna,
                               const void* bnmask, const float* bn_mean, const float* bn_rstd, const float* bn_w,
-                              const float* bn_b, float* bnsums, int bn_reps, hipStream_t st) {
-    if (!bnsums || bn_reps < 1 || (bnx && (!bn_mean || !bn_rstd))) return -1;
+                              const float* bn_b, float* bnsums, int bn_reps, float mask_scale, hipStream_t st) {
+    if (!bnsums || bn_reps < 1 || (bnx && (!bn_mean || !bn_rstd)) || !(mask_scale > 0.f)) return -1;
     if (!bnx && !bnmask && !bna) return -1;
     if (((uintptr_t)bnx | (uintptr_t)bna) & 15) return -3;
     t_bnmask = bnmask;
-    t_bnx = bnx; t_bna = bna; t_bnsums = bnsums; t_bn_reps = bn_reps;
+    t_bnx = bnx; t_bna = bna; t_bnsums = bnsums; t_bn_reps = bn_reps; t_mask_scale = mask_scale;
     t_bnp[0] = bn_mean; t_bnp[1] = bn_rstd; t_bnp[2] = bn_w; t_bnp[3] = bn_b;
     const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
                                    pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
-    t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0; t_bnmask = nullptr;
+    t_bnx = nullptr; t_bna = nullptr; t_bnsums = nullptr; t_bn_reps = 0; t_bnmask = nullptr; t_mask_scale = 1.f;
     t_bnp[0] = t_bnp[1] = t_bnp[2] = t_bnp[3] = nullptr;
     return rc;
 }

@@ -173,17 +173,25 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
     const int fh = min(oy_hi - oy_lo + 1, p.FH), fw = min(ox_hi - ox_lo + 1, p.FW);
     const float k = p.gloss[0] / fmaxf(p.sums[1], 1.f);
 
-    // low-res logits around the tile (clamped at the image border): rows are contiguous runs
+    // low-res logits around the tile (clamped at the image border).  All of a thread's loads are issued before the
+    // first LDS store (one flat index space, a fixed batch of independent loads): the row-by-row form was six
+    // dependent global round trips per block in a kernel whose blocks live ~15 us.
     {
-        const int run = (BT_W + 2) * C;
-        for (int r = 0; r < BT_H + 2; ++r) {
-            const int y = min(max(iy0 - 1 + r, 0), p.Hi - 1);
-            const bf16_raw* src = p.x + ((long)n * p.Hi + y) * p.Wi * p.ld;
-            for (int e = tid; e < run; e += kT) {
-                const int q = e / C, c = e - q * C;
-                const int x = min(max(ix0 - 1 + q, 0), p.Wi - 1);
-                lr[r * run + e] = bf2f(src[(long)x * p.ld + c]);
+        const int run = (BT_W + 2) * C, total = (BT_H + 2) * run;
+        constexpr int LB = 6;                             // loads in flight per thread and batch
+        for (int e0 = tid; e0 < total; e0 += LB * kT) {
+            bf16_raw v[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int e = min(e0 + u * kT, total - 1);
+                const int r = e / run, ee = e - r * run;
+                const int q = ee / C, c = ee - q * C;
+                const int y = min(max(iy0 - 1 + r, 0), p.Hi - 1), x = min(max(ix0 - 1 + q, 0), p.Wi - 1);
+                v[u] = p.x[(((long)n * p.Hi + y) * p.Wi + x) * p.ld + c];
             }
+#pragma unroll
+            for (int u = 0; u < LB; ++u)
+                if (e0 + u * kT < total) lr[e0 + u * kT] = bf2f(v[u]);
         }
     }
     // tap tables and the per-(tile row, footprint row) / (tile col, footprint col) weights
@@ -216,10 +224,23 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
     __syncthreads();
 
     // ---- phase 1: g for every output pixel of the footprint ----
-    for (int e = tid; e < fh * fw; e += kT) {
+    // (labels of a batch of LP pixels are loaded together, ahead of the softmax arithmetic)
+    constexpr int LP = 4;
+    for (int eb = tid; eb < fh * fw; eb += LP * kT) {
+      int tl[LP];
+#pragma unroll
+      for (int u = 0; u < LP; ++u) {
+          const int e = min(eb + u * kT, fh * fw - 1);
+          const int j = e / fw, i = e - j * fw;
+          tl[u] = ld_label<LabelT>(p.target, ((long)n * p.Ho + oy_lo + j) * p.Wo + ox_lo + i);
+      }
+#pragma unroll
+      for (int u = 0; u < LP; ++u) {
+        const int e = eb + u * kT;
+        if (e >= fh * fw) break;
         const int j = e / fw, i = e - j * fw;
         bf16_raw* gp = g + (long)e * C;
-        const int t = ld_label<LabelT>(p.target, ((long)n * p.Ho + oy_lo + j) * p.Wo + ox_lo + i);
+        const int t = tl[u];
         if (t != p.ignore_index && t >= 0 && t < C) {
             const int y0 = ytab[j], x0 = xtab[i];
             const int y1 = min(y0 + 1, p.Hi - 1), x1 = min(x0 + 1, p.Wi - 1);
@@ -265,6 +286,7 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
         } else {
             for (int c = 0; c < C; ++c) gp[c] = 0;
         }
+      }
     }
     __syncthreads();
 

@@ -93,8 +93,11 @@ class _LastConv(nn.Module):
     def forward(self, x, training: bool):
         # conv-BN-ReLU-Dropout: the dropout runs inside the BN kernels (ops.batchnorm, csrc/bn_relu.hip)
         x = conv_bn_act(getattr(self, "0"), getattr(self, "1"), x, relu=True, dropout=self.p_drop[0])
-        x = conv_bn_act(getattr(self, "4"), getattr(self, "5"), x, relu=True, dropout=self.p_drop[1])
-        return getattr(self, "8")(x)
+        # each BN+ReLU+Dropout output has ONE consumer: its BatchNorm backward prologue (mask, dropout scale, the two
+        # reductions) runs inside that consumer's data-gradient kernel
+        x = conv_bn_act(getattr(self, "4"), getattr(self, "5"), x, relu=True, dropout=self.p_drop[1],
+                        sole_consumer=True)
+        return getattr(self, "8")(x, sole_consumer=True)
 
 
 class Decoder(nn.Module):

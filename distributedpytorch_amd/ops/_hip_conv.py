@@ -11,7 +11,7 @@ a kernel.
 from __future__ import annotations
 
 import os
-from ctypes import c_int, c_long, c_void_p
+from ctypes import c_float, c_int, c_long, c_void_p
 from typing import Optional, Tuple
 
 import torch
@@ -31,7 +31,7 @@ def _lib():
         lib.dp_conv_igemm.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2.argtypes = [V, V, V, V, V] + [I] * 18 + [V]
         lib.dp_conv_igemm2r.argtypes = [V, V, V, V, V] + [I] * 18 + [V, I, V]
-        lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 9 + [I, V]
+        lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 9 + [I, c_float, V]
         lib.dp_conv_igemm2ra.argtypes = [V, V, V] + [I] * 16 + [V] * 4
         lib.dp_conv_igemm2pi.argtypes = [V, V, V] + [I] * 6 + [V, V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
@@ -371,6 +371,7 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
 
     nper = _images_per_launch(n, dy)
     bits_img = (ho * wo * (cout // 8)) if bits is not None else 0
+    mask_scale = float(holder.get("mask_scale", 1.0))      # 1/(1-p): a dropout fused behind the producer's ReLU
 
     def launch(c, sums_ptr, stream):
         st = 0
@@ -382,7 +383,7 @@ def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, d
                                         r, s, 1, sdiv, pad[0], pad[1], dil[0], dil[1], c, B.ptr(sl(residual)),
                                         B.ptr(sl(bx)), B.ptr(sl(ba)), B.ptr(mask), B.ptr(holder.get("mean")),
                                         B.ptr(holder.get("invstd")), B.ptr(holder.get("w")), B.ptr(holder.get("b")),
-                                        sums_ptr, reps, stream)
+                                        sums_ptr, reps, mask_scale, stream)
             if st != 0:
                 break
         return st
@@ -632,7 +633,7 @@ class _ConvIGemm(torch.autograd.Function):
             if dskip is not None:
                 dskip = as_nhwc(dskip)
             fused = None
-            if ctx.bn_holder is not None and cout_p == cout:
+            if ctx.bn_holder is not None and cin_p == cin:
                 fused = dgrad_bn_fused(dy, wt, (hi, wi), stride[0], pad_t, dilation, dskip, ctx.bn_holder, x)
             if fused is not None:
                 dx, part = fused
@@ -832,7 +833,7 @@ class _DepthwiseConv(torch.autograd.Function):
         ctx.weight_param = weight
         ctx.passthrough = passthrough
         # (a holder without the pre-BN tensor, ops.bnfold, is served by the dense kernels only)
-        ctx.bn_holder = bn_holder if (bn_holder and bn_holder.get("x") is not None) else None
+        ctx.bn_holder = bn_holder if (bn_holder and bn_holder.get("x") is not None and "mask_scale" not in bn_holder) else None
         outs = [y]
         if with_stats:
             if stats is None:

@@ -184,7 +184,9 @@ class _BatchNormActTrain(torch.autograd.Function):
                                                        mask_out=bits)
             if dropout is not None:
                 assert relu and residual is None
-                mask_mode, holder = 3, None
+                mask_mode = 3                # (the unfused backward recomputes the keep decisions from the seed)
+                if out is not None:
+                    holder = None
             ctx.save_for_backward(x, y if mask_mode == 1 else None, w, b, mean, invstd)
             ctx.mask_mode = mask_mode
             if holder is not None and relu:
@@ -193,8 +195,12 @@ class _BatchNormActTrain(torch.autograd.Function):
                 # (never a reference to y itself: y carries this dict as an attribute, a y -> dict -> y
                 # cycle keeps every residual activation alive until Python's cyclic GC gets to it —
                 # measured: peak HBM 232 GiB instead of 28 GiB at B64)
-                holder.update(x=x, mask_from_a=(mask_mode == 1), mean=mean, invstd=invstd, w=w, b=b,
+                # behind a fused dropout the mask source is the OUTPUT (dropped elements are zeros there: "a > 0"
+                # is "positive and kept"), and the kept elements' gradient carries the dropout scale
+                holder.update(x=x, mask_from_a=(mask_mode in (1, 3)), mean=mean, invstd=invstd, w=w, b=b,
                               mask_bits=bits)
+                if dropout is not None:
+                    holder["mask_scale"] = 65536.0 / (65536.0 - float(dropout[0]))
         else:
             mean = s / count
             var = (ss / count - mean * mean).clamp_min_(0.0)
@@ -230,6 +236,7 @@ class _BatchNormActTrain(torch.autograd.Function):
         if ctx.hip and need_dres and ctx.mask_mode == 0:
             fused_dres, need_dres = dy, False        # no activation: the residual's gradient IS dy (no copy)
         h = ctx.holder
+        drop = ctx.dropout
         if ctx.hip and h is not None and h.get("dm_ptr") == dy.data_ptr() and h.get("sums") is not None:
             # the consumer's data-gradient kernel already applied the ReLU mask to dy and left the two
             # reductions behind: no bn_bwd_reduce pass, no mask source read, the residual gradient IS dy
@@ -241,6 +248,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 part = part.sum(0, keepdim=True)  # SyncBN: one [2, C] message
             sdy, sdyx = part[0, 0], part[0, 1]
             mask_mode = 0
+            drop = None                           # mask AND dropout scale were applied by that kernel
             if need_dres:
                 fused_dres, need_dres = dy, False
         elif ctx.hip:
@@ -278,7 +286,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 # affine gradients are added into the gradient arena by the same kernel
                 from . import _hip_bn
                 dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                             mask_mode, need_dres, gw, gb, sdy, sdyx, ctx.dropout, sink_scale,
+                                             mask_mode, need_dres, gw, gb, sdy, sdyx, drop, sink_scale,
                                              sum_replicas=sum_reps)
                 if fused_dres is not None:
                     dres = fused_dres
@@ -289,7 +297,7 @@ class _BatchNormActTrain(torch.autograd.Function):
                 return dx, None, None, dres, None, None, None, None, None, None, None, None, None, None
             from . import _hip_bn
             dx, dres = _hip_bn.bwd_apply(dy, x, y, mean, invstd, w, b, g_sdy, g_sdyx, ctx.count,
-                                         mask_mode, need_dres, dropout=ctx.dropout, sum_replicas=sum_reps)
+                                         mask_mode, need_dres, dropout=drop, sum_replicas=sum_reps)
             if fused_dres is not None:
                 dres = fused_dres
             if sum_reps is not None:
@@ -376,7 +384,7 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
                                      out if B.use_hip(x) else None)
         if dropout > 0.0 and not fuse_drop:
             return F.dropout(y, dropout, True)
-        if holder and not fuse_drop:
+        if holder:
             y._dpamd_bn_holder = holder      # read by ops._hip_conv.conv2d(..., sole_consumer=True)
         return y
     if dropout > 0.0:

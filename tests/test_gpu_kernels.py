@@ -611,6 +611,48 @@ def test_graphed_eval_forward_matches_eager():
                 p.mul_(0.97)
 
 
+def test_bn_dropout_backward_prologue_in_dgrad_matches_separate_kernels():
+    """The decoder's conv-BN-ReLU-Dropout stages (models/deeplab.py, _LastConv): the consumer's data-gradient kernel
+    applies mask (from the dropped output itself: a > 0 = positive and kept), dropout scale and the two BN-backward
+    reductions (Conv2Args::mask_scale) — same gradients as the separate bn_bwd_reduce pass that recomputes the keep
+    decisions from the seed.  Also the 21-class classifier: its data gradient runs with the class channels padded
+    to 24, and still carries the prologue of the BN in front of it."""
+    from distributedpytorch_amd.models.deeplab import _LastConv
+    from distributedpytorch_amd.ops import _hip_conv, batchnorm as bn_mod
+
+    def grads(flag):
+        old = _hip_conv._BN_PROLOGUE
+        _hip_conv._BN_PROLOGUE = flag
+        try:
+            torch.manual_seed(0)
+            bn_mod._drop_calls = 100                     # the same masks on both paths
+            net = _LastConv(64, 21, mid=64).to(DEV).to(memory_format=torch.channels_last).train()
+            with torch.no_grad():
+                for m in net.modules():
+                    if hasattr(m, "running_mean"):
+                        m.weight.uniform_(0.6, 1.4); m.bias.normal_(0, 0.5)
+            x = _nhwc(_bf(torch.randn(4, 64, 33, 31, device=DEV))).requires_grad_(True)
+            t = _nhwc(_bf(torch.randn(4, 21, 33, 31, device=DEV)))
+            (net(x, True).float() - t.float()).pow(2).mean().backward()
+            g = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+            g["input"] = x.grad.detach().float().clone()
+            return g
+        finally:
+            _hip_conv._BN_PROLOGUE = old
+    counts = []
+    orig = _hip_conv.dgrad_bn_fused
+    _hip_conv.dgrad_bn_fused = lambda *a, **k: (counts.append(a[7].get("mask_scale")), orig(*a, **k))[1]
+    try:
+        g1 = grads(True)
+    finally:
+        _hip_conv.dgrad_bn_fused = orig
+    assert len(counts) == 2 and abs(counts[0] - 1 / 0.9) < 1e-3 and abs(counts[1] - 2.0) < 1e-3, counts
+    g0, g00 = grads(False), grads(False)
+    worst = max(_rel(g1[k], g0[k]) for k in g0)
+    noise = max(_rel(g00[k], g0[k]) for k in g0)
+    assert worst < max(3e-2, 8 * noise), (worst, noise, {k: _rel(g1[k], g0[k]) for k in g0})
+
+
 @pytest.mark.parametrize("block_name,hw", [("Bottleneck", (33, 31)), ("BasicBlock", (33, 31)), ("Bottleneck", (65, 67))])
 def test_bn_backward_prologue_in_dgrad_matches_separate_kernels(block_name, hw):
     """csrc/conv_igemm2.hip (Conv2Args::bnx): BN+ReLU backward's mask and reductions computed in the
