@@ -271,6 +271,10 @@ def main():
         }
         if on_gpu:
             rec["runtime"]["hbm_peak_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+            rec["runtime"]["hbm_reserved_peak_gib"] = round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)
+            # > 0: the caching allocator ran out, freed its cache (a device synchronisation) and retried — the step
+            # time then measures the allocator, not the kernels: lower the batch or set expandable segments
+            rec["runtime"]["alloc_retries"] = int(torch.cuda.memory_stats().get("num_alloc_retries", 0))
         if args.impl == "stock" and os.environ.get("MIOPEN_FIND_MODE"):
             rec["runtime"]["miopen_find_mode"] = os.environ["MIOPEN_FIND_MODE"]
         if comm_prof is not None:

@@ -468,6 +468,8 @@ struct FoldArgs {
     float* bprime;                                       // [Cout] = W t
     float* rmean2; float rm2_scale;                      // next BN's running mean += rm2_scale * b' (or null)
     int Cout, Cin;
+    bf16_raw* wfT;                                       // [Cin][Cout] or null: the folded weights transposed, for the
+                                                         //   data gradient (saves a transposing copy per layer and step)
 };
 
 __global__ __launch_bounds__(256) void bn_fold_kernel(FoldArgs a) {
@@ -517,6 +519,10 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(FoldArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc = fmaf(-g[j], m_sh[j8 + j], acc);
             *reinterpret_cast<uint4*>(wo + j8) = packed;
+            if (a.wfT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a.wfT[(long)(j8 + j) * a.Cout + k] = f2bf(g[j]);
+            }
         }
         acc = wave_sum(acc);
         __syncthreads();
@@ -849,14 +855,14 @@ DP_EXPORT int dp_bn_bwd_apply(const void* dy, const void* x, const void* y, void
 DP_EXPORT int dp_bn_fold(const float* stats, int nrep, long rep_stride, const float* gamma, const float* beta,
                          float* rmean, float* rvar, float count, float eps, float momentum, const void* w, void* wf,
                          float* s_out, float* mean_out, float* rstd_out, float* bprime, float* rmean2,
-                         float rm2_scale, int Cout, int Cin, hipStream_t st) {
+                         float rm2_scale, int Cout, int Cin, void* wfT, hipStream_t st) {
     if (!stats || !w || !wf || !s_out || !mean_out || !rstd_out || !bprime || nrep < 1 || Cin <= 0 || Cout <= 0 ||
         Cin % 8 != 0 || Cin > 8192 || count <= 0.f)
         return -1;
     if (((uintptr_t)w | (uintptr_t)wf) & 15) return -3;
     FoldArgs a{stats, nrep, rep_stride, gamma, beta, rmean, rvar, 1.f / count, eps, momentum,
                count > 1.f ? count / (count - 1.f) : 1.f, (const bf16_raw*)w, (bf16_raw*)wf, s_out, mean_out,
-               rstd_out, bprime, rmean2, rm2_scale, Cout, Cin};
+               rstd_out, bprime, rmean2, rm2_scale, Cout, Cin, (bf16_raw*)wfT};
     const int blocks = Cout < 512 ? Cout : 512;
     hipLaunchKernelGGL(bn_fold_kernel, dim3(blocks), dim3(256), (size_t)(3 * Cin + 8) * sizeof(float), st, a);
     return DP_LAUNCH_STATUS();

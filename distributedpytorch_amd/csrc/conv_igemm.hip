@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const bf16_raw* _
 // All layers at once (one launch per optimiser step instead of one per convolution in backward):
 // `table` holds, per weight tensor, {element offset in the arena, K, R, S, C, first tile}; a block
 // transposes one 32(k) x 32(c) tile of one filter tap through LDS, so both the reads (c contiguous)
-// and the writes (k contiguous) are coalesced.  src and dst arenas share offsets.
+// and the writes (k contiguous) are coalesced.  src and dst arenas share offsets.  R < 0: |R| filter rows and NO tap
+// flip — the depthwise weights ([C][3][3][1] in memory) ride along to their tap-major [9][C] form (csrc/depthwise.hip).
 struct WtSlot { long off; int K, R, S, C; int tile0; int tiles_k; };
 
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const bf16_raw* __restrict__ src,
@@ -317,9 +318,10 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const bf1
     const int tiles_c = (sl.C + 31) >> 5;
     const int tc = t % tiles_c;
     const int tap = t / tiles_c;                  // r*S + s
+    const int R = sl.R < 0 ? -sl.R : sl.R;
     const int r = tap / sl.S, s2 = tap - r * sl.S;
-    const int tapT = (sl.R - 1 - r) * sl.S + (sl.S - 1 - s2);
-    const int taps = sl.R * sl.S;
+    const int tapT = sl.R < 0 ? tap : (R - 1 - r) * sl.S + (sl.S - 1 - s2);
+    const int taps = R * sl.S;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;      // 32 x 8
     const bf16_raw* w = src + sl.off;
     bf16_raw* wt = dst + sl.off;

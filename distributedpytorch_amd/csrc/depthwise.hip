@@ -143,7 +143,10 @@ __device__ __forceinline__ Strip make_strip(int C8, long P) {
 template <int STRIP>
 __global__ __launch_bounds__(256) void dwconv2_bwd_weight_kernel(const bf16_raw* __restrict__ dy,
                                                                  const bf16_raw* __restrict__ x,
-                                                                 float* __restrict__ dw9, Dw p, int reps) {
+                                                                 float* __restrict__ dw9, Dw p, int reps, int tap_stride,
+                                                                 int ch_stride) {
+    // dw9[tap * tap_stride + channel * ch_stride]: (C, 1) = the [reps][9][C] scratch layout, (1, 9) = straight into
+    // the parameter's [C][3][3] gradient (the arena slot: no transposing add behind the kernel; reps = 1)
     __shared__ float red[kStrips][kSlab][9];       // one channel of the 8 at a time
     dw9 += (long)(blockIdx.x % (unsigned)reps) * 9 * p.C;
     const Strip s = make_strip<STRIP>(p.C >> 3, (long)p.N * p.Ho * p.Wo);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void dwconv2_bwd_weight_kernel(const bf16_raw*
             float v = 0.f;
 #pragma unroll
             for (int k = 0; k < kStrips; ++k) v += red[k][c][t];
-            atomicAdd(dw9 + t * p.C + cg * 8 + j, v);
+            atomicAdd(dw9 + (long)t * tap_stride + (long)(cg * 8 + j) * ch_stride, v);
         }
     }
 }
@@ -273,6 +276,7 @@ struct Dw4 {
     const bf16_raw* res; const bf16_raw* bna; const bf16_raw* bnx; const float* bn_mean; const float* bn_rstd;
     const float* bn_w; const float* bn_b;
     int wsplit = 1, cols_split = 1 << 30;     // column bands (dwconv4 only: maps wider than 32 * kDw4K columns)
+    int dw_ts = 0, dw_cs = 1;                 // MODE 2: strides of the weight-gradient buffer (0: tap stride = C)
 };
 
 //   MODE 0: out = depthwise conv of `in` (+ BatchNorm statistics of out);  MODE 1: see Dw4::res;
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void dwconv4_kernel(Dw4 p) {
             float v = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) v += red[(k * 8 + g) * 72 + e];
-            atomicAdd(dw + (e >> 3) * p.C + c0 + g * 8 + (e & 7), v);
+            atomicAdd(dw + (long)(e >> 3) * (p.dw_ts ? p.dw_ts : p.C) + (long)(c0 + g * 8 + (e & 7)) * p.dw_cs, v);
         }
     }
 }
@@ -656,7 +660,8 @@ struct Dw4Bn { const void* res; const void* bna; const void* bnx; const float* m
 
 template <int MODE>
 inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out, int N, int C, int H, int W, int dil,
-                      int flip, hipStream_t st, float* stats = nullptr, int stat_reps = 1, Dw4Bn bn = Dw4Bn{}) {
+                      int flip, hipStream_t st, float* stats = nullptr, int stat_reps = 1, Dw4Bn bn = Dw4Bn{},
+                      int dw_ts = 0, int dw_cs = 1) {
     const long in_bytes = (long)N * H * W * C * 2;
     if (in_bytes >= (1L << 31) - (1L << 24)) return -2;
     const int wsplit = (W + 32 * kDw4K - 1) / (32 * kDw4K);          // column bands of at most 160 columns
@@ -702,6 +707,7 @@ inline int launch_dw4(const void* in, const void* in2, const void* w9, void* out
           (const bf16_raw*)bn.res, (const bf16_raw*)bn.bna, (const bf16_raw*)bn.bnx, bn.mean, bn.rstd, bn.w, bn.b};
     p.wsplit = wsplit;
     p.cols_split = Wb;
+    p.dw_ts = dw_ts; p.dw_cs = dw_cs;
     auto kfn = dwconv4_kernel<MODE>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
@@ -756,11 +762,13 @@ DP_EXPORT int dp_dwconv_bwd_data(const void* dy, const void* w9, void* dx, int N
 // dw9: fp32 [reps][9][C], zero-initialised (or holding a gradient to accumulate into); block b adds into replica
 // b % reps.  reps = 1 is the normal call; dp_dwconv_wgrad_blocks() returns the replica count that gives every
 // block a buffer of its own (deterministic mode: no two blocks add into one address).
-DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int reps, int N, int C, int Hi, int Wi,
-                                   int Ho, int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
-    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || reps < 1) return -1;
+namespace {
+int dw_bwd_weight(const void* dy, const void* x, void* dw9, int reps, int tap_stride, int ch_stride, int N, int C, int Hi,
+                  int Wi, int Ho, int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    if (C % 8 != 0 || N <= 0 || stride < 1 || dil < 1 || reps < 1 || !dw9) return -1;
     if (dw_same(stride, pad_h, pad_w, dil, Hi, Wi, Ho, Wo)) {
-        const int rc = launch_dw4<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, st, nullptr, reps);
+        const int rc = launch_dw4<2>(x, dy, nullptr, dw9, N, C, Hi, Wi, dil, 0, st, nullptr, reps, Dw4Bn{}, tap_stride,
+                                     ch_stride);
         if (rc != -2) return rc;
     }
     Dw p{N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil};
@@ -769,8 +777,23 @@ DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int
     const long nbw = (P + kStrips * 32 - 1) / (kStrips * 32);
     if (nbw > 0x7fffffffL) return -4;
     hipLaunchKernelGGL(dwconv2_bwd_weight_kernel<32>, dim3((unsigned)nbw, (unsigned)((C8 + kSlab - 1) / kSlab)),
-                       dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p, reps);
+                       dim3(256), 0, st, (const bf16_raw*)dy, (const bf16_raw*)x, (float*)dw9, p, reps, tap_stride,
+                       ch_stride);
     return DP_LAUNCH_STATUS();
+}
+}  // namespace
+
+// dw9: fp32 [reps][9][C] (tap-major), accumulated into
+DP_EXPORT int dp_dwconv_bwd_weight(const void* dy, const void* x, void* dw9, int reps, int N, int C, int Hi, int Wi,
+                                   int Ho, int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    return dw_bwd_weight(dy, x, dw9, reps, C, 1, N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil, st);
+}
+
+// The same, added straight into the parameter's gradient: fp32 [C][3][3] (channel-major, the arena slot) — no scratch
+// buffer and no transposing add behind the kernel.
+DP_EXPORT int dp_dwconv_bwd_weight_sink(const void* dy, const void* x, void* grad, int N, int C, int Hi, int Wi, int Ho,
+                                        int Wo, int stride, int pad_h, int pad_w, int dil, hipStream_t st) {
+    return dw_bwd_weight(dy, x, grad, 1, 1, 9, N, C, Hi, Wi, Ho, Wo, stride, pad_h, pad_w, dil, st);
 }
 
 // Upper bound of the number of row blocks (grid.x, or image bands of the rolling-window kernels) any depthwise

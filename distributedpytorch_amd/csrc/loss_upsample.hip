@@ -339,3 +339,142 @@ DP_EXPORT int dp_bilinear_bwd(const void* dy, void* dx, int N, int C, int Hi, in
                               hipStream_t st) {
     return dp_bilinear_bwd_ld(dy, dx, N, C, Hi, Wi, Ho, Wo, C, st);
 }
+
+// ---- class-balanced sigmoid cross-entropy over up to 3 heads (the reference's instance task) ----------------------
+// SegmentationMultiLosses(1) on DANet's 3-tuple (`/root/reference/train_pascal.py:119`, `:199`): per head
+//   L_h = ((n_neg / n) * sum_{pos} bce + (n_pos / n) * sum_{neg} bce) / B,   L = sum_h w_h L_h.
+// As stock tensor ops that is ~25 elementwise / reduction launches per head and direction over [B,1,512,512] fp32
+// maps; here: one pass that leaves a row of partial sums PER BLOCK (no atomics: any two runs are bit-identical),
+// one single-block pass that folds them in block order into the loss and the per-head coefficients, and one pass
+// that writes the three gradients.
+namespace {
+
+constexpr int kBceHeads = 3;
+constexpr int kBceCols = 2 + 2 * kBceHeads;      // n_pos, n_neg, then (sum_pos bce, sum_neg bce) per head
+
+struct BceArgs {
+    const void* x[kBceHeads];      // logits, fp32 or bf16 (is_bf16), M elements each
+    const float* y;                // labels (>= 0.5 = positive)
+    void* dx[kBceHeads];           // backward: gradients, same dtype as the logits
+    float* part;                   // [blocks][kBceCols]
+    float* out;                    // [1 + 2 * kBceHeads]: loss, then (c_pos, c_neg) per head
+    const float* gloss;            // backward: upstream gradient (device scalar) or null (1)
+    float w[kBceHeads];
+    long M;
+    int H, is_bf16, blocks;
+    float inv_batch;
+};
+
+__device__ __forceinline__ float bce_ld(const void* p, long i, int is_bf16) {
+    return is_bf16 ? bf2f(reinterpret_cast<const bf16_raw*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+
+__global__ __launch_bounds__(256) void bce_sums_kernel(BceArgs a) {
+    float acc[kBceCols];
+#pragma unroll
+    for (int c = 0; c < kBceCols; ++c) acc[c] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.M; i += (long)gridDim.x * 256) {
+        const bool pos = a.y[i] >= 0.5f;
+        acc[pos ? 0 : 1] += 1.f;
+#pragma unroll
+        for (int h = 0; h < kBceHeads; ++h) {
+            if (h < a.H) {
+                const float x = bce_ld(a.x[h], i, a.is_bf16);
+                // stable BCE with logits: softplus(-|x|) + relu(x) - x * y
+                const float v = __logf(1.f + __expf(-fabsf(x))) + fmaxf(x, 0.f) - (pos ? x : 0.f);
+                acc[2 + 2 * h + (pos ? 0 : 1)] += v;
+            }
+        }
+    }
+    __shared__ float red[4][kBceCols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < kBceCols; ++c) {
+        const float v = wave_sum(acc[c]);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kBceCols)
+        a.part[(long)blockIdx.x * kBceCols + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void bce_final_kernel(BceArgs a) {
+    __shared__ float tot[kBceCols];
+    if (threadIdx.x < kBceCols) {
+        float v = 0.f;
+        for (int b = 0; b < a.blocks; ++b) v += a.part[(long)b * kBceCols + threadIdx.x];     // block order: fixed
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float n = fmaxf(tot[0] + tot[1], 1.f);
+        float loss = 0.f;
+        for (int h = 0; h < a.H; ++h) {
+            const float cp = a.w[h] * (tot[1] / n) * a.inv_batch, cn = a.w[h] * (tot[0] / n) * a.inv_batch;
+            loss += cp * tot[2 + 2 * h] + cn * tot[3 + 2 * h];
+            a.out[1 + 2 * h] = cp;
+            a.out[2 + 2 * h] = cn;
+        }
+        a.out[0] = loss;
+    }
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(BceArgs a) {
+    const float g = a.gloss ? a.gloss[0] : 1.f;
+    float cp[kBceHeads], cn[kBceHeads];
+#pragma unroll
+    for (int h = 0; h < kBceHeads; ++h) { cp[h] = h < a.H ? g * a.out[1 + 2 * h] : 0.f; cn[h] = h < a.H ? g * a.out[2 + 2 * h] : 0.f; }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.M; i += (long)gridDim.x * 256) {
+        const bool pos = a.y[i] >= 0.5f;
+#pragma unroll
+        for (int h = 0; h < kBceHeads; ++h) {
+            if (h < a.H) {
+                const float x = bce_ld(a.x[h], i, a.is_bf16);
+                const float d = (pos ? cp[h] : cn[h]) * (1.f / (1.f + __expf(-x)) - (pos ? 1.f : 0.f));
+                if (a.is_bf16) reinterpret_cast<bf16_raw*>(a.dx[h])[i] = f2bf(d);
+                else reinterpret_cast<float*>(a.dx[h])[i] = d;
+            }
+        }
+    }
+}
+
+inline int bce_blocks(long M) {
+    long b = (M + 256 * 8 - 1) / (256 * 8);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+}  // namespace
+
+DP_EXPORT int dp_bce_blocks(long M) { return bce_blocks(M); }
+
+// x0..x2: logits of up to 3 heads (H of them given), y: fp32 labels, part: fp32 [dp_bce_blocks(M)][8] scratch,
+// out: fp32 [7] = loss, (c_pos, c_neg) per head (read back by dp_balanced_bce_bwd)
+DP_EXPORT int dp_balanced_bce_fwd(const void* x0, const void* x1, const void* x2, int H, int is_bf16, const float* y,
+                                  long M, int batch, float w0, float w1, float w2, float* part, float* out,
+                                  hipStream_t st) {
+    if (H < 1 || H > kBceHeads || !x0 || (H > 1 && !x1) || (H > 2 && !x2) || !y || M <= 0 || batch <= 0 || !part || !out)
+        return -1;
+    BceArgs a{};
+    a.x[0] = x0; a.x[1] = x1; a.x[2] = x2; a.y = y; a.part = part; a.out = out;
+    a.w[0] = w0; a.w[1] = w1; a.w[2] = w2; a.M = M; a.H = H; a.is_bf16 = is_bf16; a.blocks = bce_blocks(M);
+    a.inv_batch = 1.f / (float)batch;
+    hipLaunchKernelGGL(bce_sums_kernel, dim3(a.blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}
+
+DP_EXPORT int dp_balanced_bce_bwd(const void* x0, const void* x1, const void* x2, int H, int is_bf16, const float* y,
+                                  long M, const float* out, const float* gloss, void* d0, void* d1, void* d2,
+                                  hipStream_t st) {
+    if (H < 1 || H > kBceHeads || !x0 || (H > 1 && !x1) || (H > 2 && !x2) || !y || M <= 0 || !out || !d0 || (H > 1 && !d1) ||
+        (H > 2 && !d2))
+        return -1;
+    BceArgs a{};
+    a.x[0] = x0; a.x[1] = x1; a.x[2] = x2; a.y = y; a.out = const_cast<float*>(out); a.gloss = gloss;
+    a.dx[0] = d0; a.dx[1] = d1; a.dx[2] = d2; a.M = M; a.H = H; a.is_bf16 = is_bf16;
+    long b = (M + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+    return DP_LAUNCH_STATUS();
+}

@@ -31,7 +31,7 @@ def _lib():
         lib.dp_bn_set_sum_replicas.argtypes = [c_int, c_long]
         lib.dp_bn_set_dropout.argtypes = [ctypes.c_uint, ctypes.c_ulonglong]
         lib.dp_bn_fold.argtypes = [c_void_p, c_int, c_long] + [c_void_p] * 4 + [c_float] * 3 + [c_void_p] * 7 + \
-            [c_float, c_int, c_int, c_void_p]
+            [c_float, c_int, c_int, c_void_p, c_void_p]
         lib.dp_bn_fold_bwd.argtypes = [c_void_p] * 11 + [c_float, c_float, c_int, c_int, c_int, c_void_p]
         lib.dp_bn3fold_rows.argtypes = [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]
         lib.dp_bn3fold_coef.argtypes = [c_void_p] * 6 + [c_float, c_float] + [c_void_p] * 5 + [c_int, c_int, c_void_p]
@@ -235,12 +235,14 @@ def bwd_apply(dy, x, y, mean, invstd, weight, bias, sdy, sdyx, count, mask_mode,
 
 
 def fold_into_pointwise(stats, weight, bias, running_mean, running_var, count, eps, momentum, w_lowp,
-                        next_running_mean=None, next_momentum=0.0):
+                        next_running_mean=None, next_momentum=0.0, transposed=False):
     """BatchNorm (training statistics ``stats`` = fp32 [R, 2, Cin] partial sums over ``count`` rows) folded
     into the bf16 [Cout, Cin, 1, 1] weights of the 1x1 convolution that consumes it.  Returns
     (w_folded bf16 KRSC, vec fp32 [3, Cin] = scale | mean | rstd, bprime fp32 [Cout] = W @ shift).
     ``next_running_mean``: the FOLLOWING BatchNorm's running mean, pre-corrected for the constant ``bprime``
-    that BN will not see (its own update then lands on the exact value)."""
+    that BN will not see (its own update then lands on the exact value).
+    ``transposed``: also return the folded weights transposed (logical [Cin, Cout, 1, 1], what the data gradient
+    multiplies with) as a 4th value — written by the same kernel."""
     cout, cin = w_lowp.shape[:2]
     if w_lowp.dtype != torch.bfloat16 or tuple(w_lowp.shape[2:]) != (1, 1) or cin % 8 or \
             not w_lowp.permute(0, 2, 3, 1).is_contiguous():
@@ -258,11 +260,14 @@ def fold_into_pointwise(stats, weight, bias, running_mean, running_var, count, e
     vec = torch.empty(3, cin, dtype=torch.float32, device=dev)
     bprime = torch.empty(cout, dtype=torch.float32, device=dev)
     rm2_scale = next_momentum / (1.0 - next_momentum) if next_running_mean is not None else 0.0
+    wft = torch.empty((cin, cout, 1, 1), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) \
+        if transposed else None
     B.check(_lib().dp_bn_fold(B.ptr(stats), int(stats.shape[0]), 2 * cin, B.ptr(weight), B.ptr(bias),
                               B.ptr(running_mean), B.ptr(running_var), float(count), float(eps), float(momentum),
                               B.ptr(w_lowp), B.ptr(wf), B.ptr(vec[0]), B.ptr(vec[1]), B.ptr(vec[2]), B.ptr(bprime),
-                              B.ptr(next_running_mean), float(rm2_scale), cout, cin, B.stream_ptr()), "bn_fold")
-    return wf, vec, bprime
+                              B.ptr(next_running_mean), float(rm2_scale), cout, cin, B.ptr(wft), B.stream_ptr()),
+            "bn_fold")
+    return (wf, vec, bprime, wft) if transposed else (wf, vec, bprime)
 
 
 def fold_backward(dwf, w_lowp, vec, weight, dw_sink, dgamma_sink, count, sink_scale=1.0, reduce_ds=None):

@@ -10,6 +10,7 @@ a kernel.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from ctypes import c_float, c_int, c_long, c_void_p
 from typing import Optional, Tuple
@@ -44,6 +45,7 @@ def _lib():
         lib.dp_dwconv_fwd_stats.argtypes = [V, V, V, V] + [I] * 11 + [V]
         lib.dp_dwconv_bwd_data.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_bwd_weight.argtypes = [V, V, V] + [I] * 11 + [V]
+        lib.dp_dwconv_bwd_weight_sink.argtypes = [V, V, V] + [I] * 10 + [V]
         lib.dp_dwconv_row_blocks.argtypes = [I] * 5
         lib.dp_dwconv_row_blocks.restype = c_long
         _sigs_done = True
@@ -671,7 +673,10 @@ class _ConvIGemm(torch.autograd.Function):
                 if cout_p != cout or cin_p != cin:
                     dw = dw[:cout, :cin]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum(dim=(0, 2, 3))[:cout]
+            # per-channel sum of the bf16 gradient in one reduction kernel (fp32 accumulation) — not an fp32 copy of the
+            # whole gradient plus a reduction (DANet's value convolution: 268 MB per step for 512 numbers)
+            from . import _hip_bn
+            db = _hip_bn.stats(dy)[0][:cout].clone()
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -805,7 +810,13 @@ class _DepthwiseConv(torch.autograd.Function):
         x = as_nhwc(x)
         ho = _out_size(hi, 3, stride[0], padding[0], dilation[0])
         wo = _out_size(wi, 3, stride[1], padding[1], dilation[1])
-        w9 = w_lowp.reshape(c, 9).t().contiguous()  # [9][C]: tap-major so 8 channels are one 16-B load
+        # [9][C]: tap-major so 8 channels are one 16-B load.  The arena keeps that copy of every depthwise weight
+        # fresh with the optimiser step's ONE transposing launch (parallel.arena); anything else transposes here.
+        w9 = getattr(weight, "_dpamd_w9", None)
+        if not (w9 is not None and getattr(weight, "_dpamd_lowpT_ok", False)
+                and getattr(weight, "_dpamd_lowp", None) is not None
+                and w_lowp.data_ptr() == weight._dpamd_lowp.data_ptr()):
+            w9 = w_lowp.reshape(c, 9).t().contiguous()
         y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ctx.set_materialize_grads(False)
         stats = None
@@ -912,15 +923,34 @@ class _DepthwiseConv(torch.autograd.Function):
                 notify(ctx.weight_param)
         elif ctx.needs_input_grad[1]:
             wreps = dw_row_blocks(nper, hi, wi, ho, wo) if B.deterministic() else 1
-            if wreps > 1:
+            wp = ctx.weight_param
+            sink = getattr(wp, "_dpamd_grad_sink", None)
+            to_sink = sink is not None and wp.grad is not None and wp.grad.data_ptr() == sink.data_ptr()
+            direct = to_sink and wreps == 1 and sink.dtype == torch.float32 and sink.numel() == 9 * c
+            if direct:
+                dw9r = dw9 = None
+            elif wreps > 1:
                 dw9r = torch.zeros(wreps, 9, c, dtype=torch.float32, device=x.device)
             else:
                 dw9r = workspace.zeros(9 * c, x.device).view(1, 9, c)
-            dw9 = dw9r[0]
-            wp = ctx.weight_param
-            sink = getattr(wp, "_dpamd_grad_sink", None)
-            if (sink is not None and wp.grad is not None and wp.grad.data_ptr() == sink.data_ptr()
-                    and streams.enabled() and _DW_WGRAD_AUX):
+            if dw9r is not None:
+                dw9 = dw9r[0]
+            if direct:
+                # straight into the arena's [C][3][3] gradient slot (channel-major strides): no scratch, no transposing
+                # add — on the auxiliary stream beside the MFMA kernels of the next backward nodes when it is on
+                aux = streams.fork(dy.device) if (streams.enabled() and _DW_WGRAD_AUX) else None
+                with torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext():
+                    for n0, n1 in spans:
+                        B.check(_lib().dp_dwconv_bwd_weight_sink(B.ptr(dy[n0:n1]), B.ptr(x[n0:n1]), B.ptr(sink), n1 - n0, c,
+                                                                 hi, wi, ho, wo, stride[0], padding[0], padding[1],
+                                                                 dilation[0], B.stream_ptr()), "dwconv_bwd_weight_sink")
+                if aux is not None:
+                    dy.record_stream(aux)
+                    x.record_stream(aux)
+                notify = getattr(wp, "_dpamd_on_grad", None)
+                if notify is not None:
+                    notify(wp)
+            elif to_sink and streams.enabled() and _DW_WGRAD_AUX:
                 # off the critical path, like the dense weight gradients: the (memory-bound) reduction runs on the
                 # auxiliary stream beside the MFMA kernels of the next backward nodes and lands in the arena
                 aux = streams.fork(dy.device)

@@ -37,6 +37,9 @@ def _lib():
         lib.dp_stem_pack.argtypes = [V, V, L, I, I, I, I, V]
         lib.dp_affine_augment2.argtypes = [V, V, V, V, V, V, V, V] + [I] * 9 + [V, V, V, V]
         lib.dp_mask_bbox.argtypes = [V, V, V, V, V, I, I, I, V]
+        lib.dp_bce_blocks.argtypes = [L]
+        lib.dp_balanced_bce_fwd.argtypes = [V, V, V, I, I, V, L, I, F, F, F, V, V, V]
+        lib.dp_balanced_bce_bwd.argtypes = [V, V, V, I, I, V, L, V, V, V, V, V, V]
         lib.dp_paste_jaccard.argtypes = [V, I, V, V, V, V, V, V, V] + [I] * 7 + [V]
         lib.dp_compose_crop.argtypes = [V, V, V, V, V, V] + [I] * 7 + [V]
         lib.dp_extreme_points.argtypes = [V, V, V, I, I, I, I, c_int, V]
@@ -449,3 +452,27 @@ def stem_pack(x: torch.Tensor, wp: int, left: int) -> torch.Tensor:
     y = torch.empty((n, h, wp, 4), dtype=torch.bfloat16, device=x.device)
     B.check(_lib().dp_stem_pack(B.ptr(x), B.ptr(y), n * h, w, c, wp, left, B.stream_ptr()), "stem_pack")
     return y
+
+
+def balanced_bce_fwd(xs, y, weights):
+    """(loss fp32 scalar view, coeff fp32 [7]) — see ops.loss.balanced_bce_multi."""
+    h, m = len(xs), xs[0].numel()
+    lib = _lib()
+    part = torch.empty(int(lib.dp_bce_blocks(m)) * 8, dtype=torch.float32, device=y.device)
+    out = torch.empty(7, dtype=torch.float32, device=y.device)
+    p = [B.ptr(t) for t in xs] + [None] * (3 - h)
+    w = [float(v) for v in weights[:h]] + [0.0] * (3 - h)
+    B.check(lib.dp_balanced_bce_fwd(p[0], p[1], p[2], h, int(xs[0].dtype == torch.bfloat16), B.ptr(y), m,
+                                    int(xs[0].shape[0]), w[0], w[1], w[2], B.ptr(part), B.ptr(out), B.stream_ptr()),
+            "balanced_bce_fwd")
+    return out
+
+
+def balanced_bce_bwd(xs, y, coeff, gloss):
+    h, m = len(xs), xs[0].numel()
+    grads = [torch.empty_like(t) for t in xs]
+    p = [B.ptr(t) for t in xs] + [None] * (3 - h)
+    d = [B.ptr(t) for t in grads] + [None] * (3 - h)
+    B.check(_lib().dp_balanced_bce_bwd(p[0], p[1], p[2], h, int(xs[0].dtype == torch.bfloat16), B.ptr(y), m, B.ptr(coeff),
+                                       B.ptr(gloss), d[0], d[1], d[2], B.stream_ptr()), "balanced_bce_bwd")
+    return grads

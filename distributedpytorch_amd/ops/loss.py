@@ -9,6 +9,8 @@ nothing but the logits held between forward and backward).
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -98,3 +100,37 @@ class SoftmaxCrossEntropy(nn.Module):
                 main = main + 0.4 * softmax_cross_entropy(aux, target, self.ignore_index)
             return main
         return softmax_cross_entropy(logits, target, self.ignore_index)
+
+
+class _BalancedBceHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, weights, *xs):
+        from . import _hip_misc
+        xs = tuple(t.contiguous() for t in xs)
+        coeff = _hip_misc.balanced_bce_fwd(xs, y, weights)
+        ctx.save_for_backward(y, coeff, *xs)
+        return coeff[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _hip_misc
+        y, coeff, *xs = ctx.saved_tensors
+        grads = _hip_misc.balanced_bce_bwd(xs, y, coeff, g.detach().float().contiguous())
+        return (None, None, *grads)
+
+
+def balanced_bce_multi(outputs, target: torch.Tensor, weights) -> Optional[torch.Tensor]:
+    """``sum_h w_h * class_balanced_cross_entropy_loss(outputs[h], target, size_average=False, batch_average=True)``
+    for up to 3 heads in three kernel launches (csrc/loss_upsample.hip) — or ``None`` when the fused kernels do not
+    take the call (CPU tensors, the stock-op backend, more than 3 heads, mixed shapes / dtypes): the caller then runs
+    the tensor-op formulation (utils.losses)."""
+    outputs = tuple(outputs)
+    if not (1 <= len(outputs) <= 3) or not B.use_hip(outputs[0]):
+        return None
+    o0 = outputs[0]
+    if o0.dtype not in (torch.float32, torch.bfloat16) or target.numel() != o0.numel():
+        return None
+    if any(o.shape != o0.shape or o.dtype != o0.dtype or o.device != o0.device for o in outputs):
+        return None
+    y = target.detach().reshape(o0.shape).float().contiguous()
+    return _BalancedBceHip.apply(y, tuple(float(w) for w in weights), *outputs)

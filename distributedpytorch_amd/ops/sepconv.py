@@ -71,8 +71,11 @@ class _FoldedPointwise(torch.autograd.Function):
             _small_all_reduce(stats1.view(-1), ctx.pg)
             count *= dist.get_world_size(ctx.pg)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        wf, vec, _ = _hip_bn.fold_into_pointwise(stats1, g32, b32, bn1.running_mean, bn1.running_var, count, bn1.eps,
-                                                 bn1.momentum, w_lowp, bn2.running_mean, bn2.momentum)
+        need_t = bool(ctx.needs_input_grad[0])
+        wf, vec, _, *wft = _hip_bn.fold_into_pointwise(stats1, g32, b32, bn1.running_mean, bn1.running_var, count,
+                                                       bn1.eps, bn1.momentum, w_lowp, bn2.running_mean, bn2.momentum,
+                                                       transposed=need_t)
+        ctx.wft = wft[0] if wft else None         # (not a saved tensor: never an input or output of this node)
         reps = _hip_conv.stat_replicas(n * h * w)
         stats2 = _hip_conv.stats_buffer(reps, cout, z.device)
         y = _hip_conv.igemm(z, wf, (h, w), 1, 1, (0, 0), (1, 1), None, stats2)
@@ -88,17 +91,18 @@ class _FoldedPointwise(torch.autograd.Function):
     def backward(ctx, dy, _unused=None):
         if dy is None:
             return (None,) * 9
-        from . import _hip_bn, _hip_conv, streams
+        from . import _hip_bn, _hip_conv, streams, workspace
         from .batchnorm import _small_all_reduce
         z, wf, w_lowp, vec, g32 = ctx.saved_tensors
+        wft = ctx.wft if ctx.wft is not None else _hip_conv.weight_transpose(wf)
         gamma, beta, weight = ctx.params
         cout, cin = wf.shape[:2]
         n, _, h, w = z.shape
         dy = _hip_bn.as_nhwc(dy)
         # 1. weight gradient w.r.t. the folded weights (needed first: ds, hence the data gradient's statistics
         #    term, comes out of it)
-        dwf = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=z.device,
-                          memory_format=torch.channels_last).zero_()
+        # (a slice of the per-step zeroed pool — one memset per step — not a fill launch per layer)
+        dwf = workspace.zeros(cout * cin, z.device).view(cout, 1, 1, cin).permute(0, 3, 1, 2)
         serial = _SERIAL or not streams.enabled()
         aux = None
         if serial:
@@ -114,7 +118,7 @@ class _FoldedPointwise(torch.autograd.Function):
         dz = None
         if need_dz and not serial:
             # data gradient beside the weight gradient; the statistics term is a separate pass behind both
-            dz = _hip_conv.igemm(dy, _hip_conv.weight_transpose(wf), (h, w), 1, 1, (0, 0), (1, 1))
+            dz = _hip_conv.igemm(dy, wft, (h, w), 1, 1, (0, 0), (1, 1))
         if aux is not None:
             torch.cuda.current_stream(z.device).wait_stream(aux)
         w_sink = _sink_of(weight) if ctx.needs_input_grad[3] else None
@@ -133,7 +137,7 @@ class _FoldedPointwise(torch.autograd.Function):
                                    g_sink if g_sink is not None else dgamma, ctx.count, sink_scale, reduce_ds)
         if need_dz and serial:
             # 2. dz = W'^T dy + c * z - c * mean in ONE kernel: the statistics term rides in the store loop
-            dz = _hip_conv.igemm(dy, _hip_conv.weight_transpose(wf), (h, w), 1, 1, (0, 0), (1, 1),
+            dz = _hip_conv.igemm(dy, wft, (h, w), 1, 1, (0, 0), (1, 1),
                                  residual=z, residual_affine=cc)
         elif need_dz:
             _hip_bn.affine_add_(dz, z, cc[0], cc[1])

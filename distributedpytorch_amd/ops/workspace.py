@@ -13,7 +13,8 @@ from typing import Dict
 
 import torch
 
-_POOL_FLOATS = 8 << 20   # 32 MiB
+_POOL_FLOATS = 64 << 20   # 256 MiB of the 288 GB (the folded separable units' weight-gradient scratch: 63 x 2.4 MB per
+                          # Xception-65 step); only what a step handed out is zeroed again
 _ALIGN = 64
 
 

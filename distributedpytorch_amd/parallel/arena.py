@@ -168,7 +168,7 @@ class ParamArena:
             return
         import numpy as np
         recs, tile0 = [], 0
-        dense = []
+        dense, depthwise = [], []
         for s in self.slots:
             p = s.param
             if p.dim() == 4 and p.shape[1] > 1 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0:
@@ -177,6 +177,15 @@ class ParamArena:
                 recs.append((s.offset, k, r, sw, c, tile0, tiles_k))
                 tile0 += r * sw * tiles_k * ((c + 31) // 32)
                 dense.append(s)
+            elif p.dim() == 4 and p.shape[1] == 1 and tuple(p.shape[2:]) == (3, 3) and p.shape[0] % 8 == 0:
+                # depthwise [C,1,3,3]: the kernels read tap-major [9][C] weights (8 channels = one 16-byte load); the
+                # same launch keeps that copy fresh (R < 0: no tap flip) instead of one transposing copy per layer
+                # and step in forward (65 launches per Xception-65 step)
+                k = p.shape[0]
+                tiles_k = (k + 31) // 32
+                recs.append((s.offset, k, -3, 3, 1, tile0, tiles_k))
+                tile0 += 9 * tiles_k
+                depthwise.append(s)
         if not recs:
             return
         tab = np.zeros(len(recs), dtype=np.dtype([("off", "<i8"), ("K", "<i4"), ("R", "<i4"), ("S", "<i4"),
@@ -192,7 +201,10 @@ class ParamArena:
             # logical [Cin, Cout, R, S] stored channels-last = memory [c][r][s][k]
             s.param._dpamd_lowpT = seg.view(c, r, sw, k).permute(0, 3, 1, 2)
             s.param._dpamd_lowpT_ok = False
-        self._wt_dense = dense
+        for s in depthwise:
+            s.param._dpamd_w9 = self.flat_lowpT[s.offset:s.offset + s.numel].view(9, s.param.shape[0])
+            s.param._dpamd_lowpT_ok = False
+        self._wt_dense = dense + depthwise
         self.refresh_transposed()
 
     def refresh_transposed(self) -> None:

@@ -59,6 +59,12 @@ class SegmentationMultiLosses(nn.Module):
     def forward(self, outputs, target):
         if torch.is_tensor(outputs):
             outputs = (outputs,)
+        if self.nclass == 1:
+            # the three heads' balanced BCE in three launches (ops.loss.balanced_bce_multi) where the kernels run
+            from ..ops.loss import balanced_bce_multi
+            fused = balanced_bce_multi(outputs[:len(self.weights)], target, self.weights)
+            if fused is not None:
+                return fused
         total = None
         for w, o in zip(self.weights, outputs):
             term = self._one(o, target) * w

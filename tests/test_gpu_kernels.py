@@ -840,3 +840,31 @@ def test_inplace_concat_matches_torch_cat(train):
     worst = max(_rel(g1[k], g0[k]) for k in g0)
     noise = max(_rel(g00[k], g0[k]) for k in g0)        # atomics order of the fused statistics
     assert worst < max(3e-2, 6 * noise), (worst, noise)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads", [1, 3])
+def test_balanced_bce_multi_matches_the_tensor_op_formulation(dtype, heads):
+    """csrc/loss_upsample.hip bce_* kernels: SegmentationMultiLosses(1) over DANet's heads
+    (`/root/reference/train_pascal.py:119`, `:199`) in three launches == utils.losses.class_balanced_cross_entropy_loss
+    per head in fp32 tensor ops, value and gradients; two runs bit-identical (per-block partial sums, no atomics)."""
+    from distributedpytorch_amd.utils.losses import SegmentationMultiLosses, class_balanced_cross_entropy_loss
+    g = torch.Generator().manual_seed(heads)
+    outs = [(torch.randn(5, 1, 67, 45, generator=g) * 3).to(dtype).to(DEV).requires_grad_(True) for _ in range(heads)]
+    target = (torch.rand(5, 1, 67, 45, generator=g) > 0.7).float().to(DEV)
+    weights = (1.0, 0.4, 0.25)
+    crit = SegmentationMultiLosses(1, weights)
+    loss = crit(tuple(outs) if heads > 1 else outs[0], target)
+    (loss * 2.5).backward()
+    refs = [o.detach().float().clone().requires_grad_(True) for o in outs]
+    want = sum(w * class_balanced_cross_entropy_loss(r, target, size_average=False, batch_average=True)
+               for w, r in zip(weights, refs))
+    (want * 2.5).backward()
+    assert abs(float(loss) - float(want)) < 2e-4 * abs(float(want)) + 1e-5, (float(loss), float(want))
+    for o, r in zip(outs, refs):
+        assert o.grad.dtype == dtype
+        assert _rel(o.grad.float(), r.grad) < (1e-5 if dtype == torch.float32 else 6e-3)
+    outs2 = [o.detach().clone().requires_grad_(True) for o in outs]
+    loss2 = crit(tuple(outs2) if heads > 1 else outs2[0], target)
+    (loss2 * 2.5).backward()
+    assert torch.equal(loss, loss2) and all(torch.equal(a.grad, b.grad) for a, b in zip(outs, outs2))

@@ -41,11 +41,11 @@ def timeit(fn, iters=5, inner=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--gen", type=int, default=0, help="depthwise kernel generation (0: the library's default)")
+    ap.add_argument("--flat", action="store_true", help="the flat kernels instead of the rolling-window ones")
     args = ap.parse_args()
     from distributedpytorch_amd.ops import _hip_conv
-    if args.gen:
-        _hip_conv._lib().dp_dwconv_set_gen(args.gen)
+    if args.flat:
+        _hip_conv._lib().dp_dwconv_set_window(0)
     tot = [0.0, 0.0, 0.0]
     for name, cnt, c, hw, d in SHAPES:
         x = torch.randn(args.batch, c, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -67,7 +67,7 @@ def main():
                                                B.stream_ptr()))
         t_dx = timeit(lambda: lib.dp_dwconv_bwd_data(B.ptr(dy), B.ptr(w9), B.ptr(dx), args.batch, c, hw_, hw_, hw_, hw_, 1,
                                                      d, d, d, B.stream_ptr()))
-        t_w = timeit(lambda: lib.dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), args.batch, c, hw_, hw_, hw_, hw_, 1,
+        t_w = timeit(lambda: lib.dp_dwconv_bwd_weight(B.ptr(dy), B.ptr(x), B.ptr(dw9), 1, args.batch, c, hw_, hw_, hw_, hw_, 1,
                                                       d, d, d, B.stream_ptr()))
         mb = x.numel() * 2 / 1e6
         print(f"{name:18s} x{cnt:2d} {mb:7.1f} MB | fwd {t_f:7.1f} us ({2 * mb / t_f:5.2f} TB/s) | dgrad {t_dx:7.1f} us "
