@@ -661,8 +661,7 @@ class _ConvIGemm(torch.autograd.Function):
                     aux = streams.fork(dy.device)
                     with torch.cuda.stream(aux):
                         wgrad(dy, x, (cout, cin, r, s), stride, padding, dilation, out=sink)
-                    dy.record_stream(aux)
-                    x.record_stream(aux)
+                    streams.keep_alive(dy, x)
                 else:
                     wgrad(dy, x, (cout, cin, r, s), stride, padding, dilation, out=sink)
                 notify = getattr(wp, "_dpamd_on_grad", None)
@@ -945,8 +944,7 @@ class _DepthwiseConv(torch.autograd.Function):
                                                                  hi, wi, ho, wo, stride[0], padding[0], padding[1],
                                                                  dilation[0], B.stream_ptr()), "dwconv_bwd_weight_sink")
                 if aux is not None:
-                    dy.record_stream(aux)
-                    x.record_stream(aux)
+                    streams.keep_alive(dy, x)
                 notify = getattr(wp, "_dpamd_on_grad", None)
                 if notify is not None:
                     notify(wp)
@@ -960,9 +958,7 @@ class _DepthwiseConv(torch.autograd.Function):
                                                             hi, wi, ho, wo, stride[0], padding[0], padding[1], dilation[0],
                                                             B.stream_ptr()), "dwconv_bwd_weight")
                     sink.view(c, 9).add_((dw9r.sum(0) if wreps > 1 else dw9).t())
-                dy.record_stream(aux)
-                x.record_stream(aux)
-                dw9r.record_stream(aux)      # (a pool slice or a fresh tensor: either way written and read on aux)
+                streams.keep_alive(dy, x, dw9r)     # (dw9r: a pool slice or a fresh tensor, written and read on aux)
                 notify = getattr(wp, "_dpamd_on_grad", None)
                 if notify is not None:
                     notify(wp)

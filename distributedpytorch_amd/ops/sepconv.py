@@ -111,9 +111,7 @@ class _FoldedPointwise(torch.autograd.Function):
             aux = streams.fork(z.device)
             with torch.cuda.stream(aux):
                 _hip_conv.wgrad(dy, z, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=dwf)
-            dy.record_stream(aux)
-            z.record_stream(aux)
-            dwf.record_stream(aux)
+            streams.keep_alive(dy, z)
         need_dz = ctx.needs_input_grad[0]
         dz = None
         if need_dz and not serial:

@@ -9,7 +9,12 @@ they fill the CUs the dgrad → BN-backward chain leaves free.
 
 Ordering contract
 * ``fork()``    — aux waits for everything enqueued on the current stream so far (``dy`` is ready);
-* tensors read on aux are ``record_stream``-ed so the caching allocator does not recycle them early;
+* tensors read on aux are handed to ``keep_alive()``: the section holds a reference until the current stream has
+  waited for that section (a few forks later, or at ``join()``), so their memory returns to the allocator in stream
+  order.  NOT ``record_stream``: that holds a block back until the GPU has passed an event recorded when the HOST
+  released the tensor, and the host runs up to a whole backward ahead of the GPU — every block read by a weight
+  gradient stayed unusable for most of the step and the allocator reserved twice what was allocated (R101 B256: 168
+  vs 81 GiB; Xception-65 OS8 at B128 filled the device: profiles/r3_aux_stream_memory.md);
 * ``join()``    — the current stream waits for everything enqueued on aux (call before the gradients
   are consumed: bucket all-reduce, optimiser step).
 """
@@ -97,12 +102,43 @@ def aux_stream(device: Optional[torch.device] = None) -> "torch.cuda.Stream":
     return pool[k]
 
 
+# A forked section = the work queued on the aux stream between two fork() calls + the tensors it reads.  The current
+# stream waits for a section _MAX_LAG forks after it was opened (a GPU-side wait that costs nothing: the weight
+# gradients are shorter than the dgrad -> BN-backward chain between two forks; measured identical step times for 2..16)
+# and only then are the section's tensors released on the host.
+_MAX_LAG = 4
+_sections: Dict[int, list] = {}          # device -> [[end event or None, [tensors]], ...], oldest first
+
+
 def fork(device: Optional[torch.device] = None) -> "torch.cuda.Stream":
     """Make the aux stream wait for the current stream's work so far and return it."""
     st = aux_stream(device)
-    st.wait_stream(torch.cuda.current_stream(st.device))
-    _dirty[st.device.index] = True
+    idx = st.device.index
+    cur = torch.cuda.current_stream(st.device)
+    q = _sections.setdefault(idx, [])
+    if q and q[-1][0] is None:
+        ev = torch.cuda.Event()
+        ev.record(st)                    # the end of the section opened by the previous fork
+        q[-1][0] = ev
+    while len(q) > _MAX_LAG:
+        ev, keep = q.pop(0)
+        cur.wait_event(ev)
+        keep.clear()                     # released behind the wait: reusable by the current stream in stream order
+    q.append([None, []])
+    st.wait_stream(cur)
+    _dirty[idx] = True
     return st
+
+
+def keep_alive(*tensors: Optional[torch.Tensor]) -> None:
+    """The tensors are read by the section opened by the last ``fork()`` of their device: hold them until the current
+    stream has waited for that section (see the module docstring)."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            q = _sections.get(t.device.index)
+            if not q:
+                raise RuntimeError("streams.keep_alive outside a forked section")
+            q[-1][1].append(t)
 
 
 def join(device: Optional[torch.device] = None) -> None:
@@ -113,6 +149,10 @@ def join(device: Optional[torch.device] = None) -> None:
         for st in _streams[idx]:
             cur.wait_stream(st)
         _dirty[idx] = False
+    q = _sections.pop(idx, None)         # everything forked so far is behind the current stream now
+    if q:
+        for _ev, keep in q:
+            keep.clear()
 
 
 def join_into(stream: "torch.cuda.Stream", device: Optional[torch.device] = None) -> None:

@@ -94,8 +94,7 @@ class TrainEngine:
         last_micro = (self._micro + 1) % self.accum_steps == 0
         if self.on_gpu:
             # The loss is never read on the host, so nothing stops Python from queueing steps faster than
-            # the GPU retires them; tensors the aux stream still holds (record_stream) cannot be
-            # recycled meanwhile and the caching allocator grows without bound (B128: 280 GiB, OOM).
+            # the GPU retires them, and the caching allocator then grows without bound (B128: 280 GiB, OOM).
             # Wait for the step before the previous one: two steps in flight keep the queues full.
             if len(self._step_events) >= 2:
                 self._step_events.pop(0).synchronize()

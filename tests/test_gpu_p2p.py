@@ -38,15 +38,18 @@ def _worker(rank, world, port, sync_bn_case):
         t = torch.randn(4096, device="cuda", generator=g)
         mine = t.clone()
         ar.all_reduce_(t)
+        # (gloo collectives of the checks run on host tensors: its device-tensor path stalled now and then with two
+        # processes on one GPU)
+        mine = mine.cpu()
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         want = parts[0].clone()
         for p in parts[1:]:
             want += p                                  # rank order, as the kernel sums
-        assert torch.equal(t, want)
-        ref = t.clone()
+        assert torch.equal(t.cpu(), want)
+        ref = t.cpu()
         dist.broadcast(ref, src=0)
-        assert torch.equal(ref, t), "ranks must hold bit-identical results"
+        assert torch.equal(ref, t.cpu()), "ranks must hold bit-identical results"
         if sync_bn_case:
             # SyncBN through the one-shot kernel == BN over the concatenated batch
             from distributedpytorch_amd import ops
@@ -68,9 +71,9 @@ def _worker(rank, world, port, sync_bn_case):
             # affine gradients: whatever each rank holds, the SUM over the ranks (world x DDP's average) is the
             # full-batch gradient
             for prm, ref in ((bn.weight, bn_ref.weight), (bn.bias, bn_ref.bias)):
-                gsum = prm.grad.detach().clone()
+                gsum = prm.grad.detach().cpu()
                 dist.all_reduce(gsum)
-                assert torch.allclose(gsum, ref.grad, atol=2e-2 * float(ref.grad.abs().max()), rtol=2e-2)
+                assert torch.allclose(gsum, ref.grad.cpu(), atol=2e-2 * float(ref.grad.abs().max()), rtol=2e-2)
             # and through a convolution's fused statistics (replicated partial sums all-reduced in place)
             conv = ops.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
             torch.manual_seed(4)
@@ -186,10 +189,12 @@ def _fold_sync_worker(rank, world, port):
             assert cos(y.float(), yr[sl].float()) > 0.9999, (case, cos(y.float(), yr[sl].float()))
             assert cos(x.grad.float(), xr.grad[sl].float()) > 0.995, (case, cos(x.grad.float(), xr.grad[sl].float()))
             for (k, prm), (_, rp) in zip(net.named_parameters(), ref.named_parameters()):
-                gsum = prm.grad.detach().float().clone()
+                # (on the host: gloo's device-tensor path stalled now and then with two processes on one GPU — both
+                # ranks inside this all_reduce, no kernel outstanding; the watchdog above named the line)
+                gsum = prm.grad.detach().float().cpu()
                 dist.all_reduce(gsum)                       # world x DDP's average = the full-batch gradient
                 if float(rp.grad.norm()) > 1e-3:
-                    assert cos(gsum, rp.grad.float()) > 0.995, (case, k, cos(gsum, rp.grad.float()))
+                    assert cos(gsum, rp.grad.float().cpu()) > 0.995, (case, k, cos(gsum, rp.grad.float().cpu()))
             for (k, b), (_, rb) in zip(net.named_buffers(), ref.named_buffers()):
                 if k.endswith("running_mean") or k.endswith("running_var"):
                     assert torch.allclose(b, rb, atol=2e-2, rtol=2e-2), (case, k)

@@ -149,6 +149,35 @@ def test_paste_jaccard_kernel_matches_the_host_formulation():
     assert (no_void[:, 0, 1] >= ref[:, 1, 1] - 6).all()
 
 
+@pytest.mark.parametrize("task", ["instance", "semseg"])
+def test_entrypoint_validates_on_the_device(task, tmp_path):
+    """with --data-path gpu the entrypoint's validation runs on the device too (device sample store,
+    device transform chain, paste_jaccard / confusion-matrix kernels, one host read per epoch) and logs its
+    throughput; the numbers equal the host validation (--val-path cpu) of the same weights."""
+    import json
+
+    import train_pascal as tp
+    from distributedpytorch_amd import ops
+    model = "danet_resnet50" if task == "instance" else "deeplabv3plus_resnet18"
+    common = ["--task", task, "--synthetic", "--model", model, "--crop", "128" if task == "instance" else "129",
+              "--nEpochs", "1", "--trainBatch", "4", "--testBatch", "4", "--synthetic-len", "48", "--workers", "0",
+              "--log-every", "0", "--max-iters", "3", "--seed", "3"]
+    vals = {}
+    with ops.deterministic_mode(True):            # the same weights after the same three steps on both runs
+        for path in ("auto", "cpu"):
+            d = tmp_path / path
+            tp.main(common + ["--save-dir", str(d), "--val-path", path])
+            recs = [json.loads(l) for l in (d / "run_0" / "log.jsonl").read_text().splitlines()]
+            vals[path] = next(r for r in recs if r.get("kind") == "val")
+    assert vals["auto"]["path"] == "device" and vals["cpu"]["path"] == "host"
+    assert vals["auto"]["img_per_s"] > 0
+    if task == "instance":
+        for a, b in zip(vals["auto"]["JACCARD"], vals["cpu"]["JACCARD"]):
+            assert abs(a - b) < 5e-3, vals
+    else:
+        assert abs(vals["auto"]["mIoU"] - vals["cpu"]["mIoU"]) < 5e-3, vals
+
+
 def test_gpu_batch_loader_feeds_engine():
     """train_pascal's GPU data path: device sample store -> gather -> TrainEngine (both tasks)."""
     from distributedpytorch_amd.data import SyntheticVOC
