@@ -314,103 +314,10 @@ __global__ __launch_bounds__(kT) void upsample_ce_bwd_kernel(UpCeArgs p) {
     }
 }
 
-// ---- backward, exact scale 4 (Ho = 4 (Hi - 1) + 1: the 129 -> 513 head) ----------------------------------------------
-// The gather form above recomputes the softmax of 1.63x the output pixels (4 x 8 low-res tile, 22 x 38 footprint),
-// stages the whole gradient map of the footprint in LDS and reads 49 taps per output element: 3.5 ms at B256 for
-// ~1 ms of arithmetic.  Here a block owns an 8 x 16 low-res tile and every thread takes ONE full-resolution pixel of
-// the 36 x 68 footprint (1.2x): interpolated logits from a bf16 halo tile (12 ds_read_b128), softmax in registers,
-// and the gradient goes straight to the pixel's four low-res taps.  At scale 4 the four pixels ox = 4q .. 4q + 3
-// share their taps (columns q, q + 1), so a quad first reduces its (1 - fx) g and fx g sums with two DPP exchanges and
-// each of its four lanes adds ONE of the four (row, column) targets into an fp32 LDS tile with ds_add_f32 — a quarter
-// of the atomics, no two lanes of a quad on one address.
-constexpr int B4_TH = 8, B4_TW = 16;
-
-template <typename LabelT, int CP>
-__global__ __launch_bounds__(kT) void upsample_ce_bwd4_kernel(UpCeArgs p) {
-    constexpr int HR = B4_TH + 2, HC = B4_TW + 2;          // halo tile: rows iy0-1 .. iy0+TH, cols ix0-1 .. ix0+TW
-    constexpr int FR = (B4_TH + 1) * 4, FC = (B4_TW + 1) * 4;   // footprint: quads qy = iy0-1 .. iy0+TH-1 (x likewise)
-    __shared__ __attribute__((aligned(16))) bf16_raw lr[HR * HC * CP];
-    __shared__ float acc[B4_TH * B4_TW * CP];
-    const int C = p.C;
-    const int tid = threadIdx.x;
-    int b = blockIdx.x;
-    const int tx = b % p.tiles_x; b /= p.tiles_x;
-    const int ty = b % p.tiles_y;
-    const int n = b / p.tiles_y;
-    const int iy0 = ty * B4_TH, ix0 = tx * B4_TW;
-    const float k = p.gloss[0] / fmaxf(p.sums[1], 1.f);
-    for (int e = tid; e < B4_TH * B4_TW * CP; e += kT) acc[e] = 0.f;
-    for (int e = tid; e < HR * HC * CP; e += kT) {
-        const int c = e % CP, q = (e / CP) % HC, r = e / (CP * HC);
-        const int y = min(max(iy0 - 1 + r, 0), p.Hi - 1), x = min(max(ix0 - 1 + q, 0), p.Wi - 1);
-        lr[e] = c < C ? p.x[(((long)n * p.Hi + y) * p.Wi + x) * p.ld + c] : (bf16_raw)0;
-    }
-    __syncthreads();
-    for (int e0 = 0; e0 < FR * FC; e0 += kT) {
-        const int e = e0 + tid;                            // FR * FC and kT are multiples of 4: quads stay whole
-        const int j = e / FC, i = e - j * FC;
-        const int qy = iy0 - 1 + (j >> 2), qx = ix0 - 1 + (i >> 2);
-        const int oy = 4 * qy + (j & 3), ox = 4 * qx + (i & 3);
-        const bool inside = e < FR * FC && qy >= 0 && qx >= 0 && oy < p.Ho && ox < p.Wo;
-        const float fy = 0.25f * (float)(j & 3), fx = 0.25f * (float)(i & 3);
-        float g[CP];
-#pragma unroll
-        for (int c = 0; c < CP; ++c) g[c] = 0.f;
-        int t = -1;
-        if (inside) t = ld_label<LabelT>(p.target, ((long)n * p.Ho + oy) * p.Wo + ox);
-        if (inside && t != p.ignore_index && t >= 0 && t < C) {
-            // halo-tile coordinates of the taps: row qy -> (qy - (iy0 - 1)) = j >> 2, the next row one further
-            const int r0 = j >> 2, c0 = i >> 2;
-            const int r1 = min(qy + 1, p.Hi - 1) - (iy0 - 1), c1 = min(qx + 1, p.Wi - 1) - (ix0 - 1);
-            const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
-            const uint4* t00 = reinterpret_cast<const uint4*>(lr + (r0 * HC + c0) * CP);
-            const uint4* t01 = reinterpret_cast<const uint4*>(lr + (r0 * HC + c1) * CP);
-            const uint4* t10 = reinterpret_cast<const uint4*>(lr + (r1 * HC + c0) * CP);
-            const uint4* t11 = reinterpret_cast<const uint4*>(lr + (r1 * HC + c1) * CP);
-            float m = -3.0e38f;
-#pragma unroll
-            for (int c8 = 0; c8 < CP / 8; ++c8) {
-                float a0[8], a1[8], a2[8], a3[8];
-                unpack8(t00[c8], a0); unpack8(t01[c8], a1); unpack8(t10[c8], a2); unpack8(t11[c8], a3);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c8 * 8 + u;
-                    g[c] = c < C ? w00 * a0[u] + w01 * a1[u] + w10 * a2[u] + w11 * a3[u] : -3.0e38f;
-                    m = fmaxf(m, g[c]);
-                }
-            }
-            float ssum = 0.f;
-#pragma unroll
-            for (int c = 0; c < CP; ++c) { g[c] = c < C ? __expf(g[c] - m) : 0.f; ssum += g[c]; }
-            const float inv = k / ssum;
-#pragma unroll
-            for (int c = 0; c < CP; ++c) g[c] = c < C ? g[c] * inv - (c == t ? k : 0.f) : 0.f;
-        }
-        // quad sums of (1 - fx) g and fx g, then lane r of the quad adds target (row qy + (r >> 1), col qx + (r & 1))
-        const int r = tid & 3;
-        const int trow = qy + (r >> 1) - iy0, tcol = qx + (r & 1) - ix0;
-        const bool tgt_ok = e < FR * FC && trow >= 0 && trow < B4_TH && tcol >= 0 && tcol < B4_TW &&
-                            iy0 + trow < p.Hi && ix0 + tcol < p.Wi;
-        float* dst = acc + (trow * B4_TW + tcol) * CP;
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            float a = (1.f - fx) * g[c], bb = fx * g[c];
-            a += __shfl_xor(a, 1, 64); bb += __shfl_xor(bb, 1, 64);
-            a += __shfl_xor(a, 2, 64); bb += __shfl_xor(bb, 2, 64);
-            // rows: this lane's OWN pixel row weight is not what counts — all four lanes of a quad share oy, so the
-            // quad's sums belong to row qy with (1 - fy) and to row qy + 1 with fy
-            const float v = ((r & 1) ? bb : a) * ((r >> 1) ? fy : 1.f - fy);
-            if (tgt_ok && c < C && v != 0.f) atomicAdd(dst + c, v);
-        }
-    }
-    __syncthreads();
-    const int th = min(B4_TH, p.Hi - iy0), tw = min(B4_TW, p.Wi - ix0);
-    for (int e = tid; e < th * tw * p.ldo; e += kT) {
-        const int pix = e / p.ldo, c = e - pix * p.ldo;
-        const int rr = pix / tw, q = pix - rr * tw;
-        p.dx[(((long)n * p.Hi + iy0 + rr) * p.Wi + ix0 + q) * p.ldo + c] = f2bf(c < C ? acc[(rr * B4_TW + q) * CP + c] : 0.f);
-    }
-}
+// (Two pixel-centric forms of the backward for the exact scale-4 head were built and measured in round 3 — every
+// thread one full-resolution pixel, contributions added into an LDS tile with ds_add_f32: 7.3 ms; the 4 x 4 pixels of a
+// low-res cell reduced by DPP rotations inside a 16-lane row, no atomics: 3.85 ms — against 3.47 ms of the gather form
+// above at B256.  Neither is kept; profiles/r3_loss_backward_scale4_negative.md has the kernels' description and times.)
 
 inline bool fill_args(UpCeArgs& p, int N, int C, int ld, int Hi, int Wi, int Ho, int Wo, int ignore_index) {
     if (N <= 0 || C <= 0 || ld < C || Hi <= 0 || Wi <= 0 || Ho < Hi || Wo < Wi) return false;
@@ -462,16 +369,6 @@ DP_EXPORT int dp_upsample_ce_bwd(const void* x, const void* target, int label_ki
     if (lds > 64 * 1024) return -2;
     p.x = (const bf16_raw*)x; p.target = target; p.sums = const_cast<float*>(sums); p.gloss = gloss;
     p.dx = (bf16_raw*)dx; p.ldo = ldo;
-    if (Hi > 1 && Wi > 1 && Ho == 4 * (Hi - 1) + 1 && Wo == 4 * (Wi - 1) + 1 && C <= 24 && ldo <= 24) {
-        // exact scale 4: the pixel-centric kernel
-        p.tiles_y = (Hi + B4_TH - 1) / B4_TH; p.tiles_x = (Wi + B4_TW - 1) / B4_TW;
-        const long grid4 = (long)N * p.tiles_y * p.tiles_x;
-        if (grid4 > 0x7fffffffL) return -2;
-        if (label_kind == 0) hipLaunchKernelGGL((upsample_ce_bwd4_kernel<unsigned char, 24>), dim3((unsigned)grid4), dim3(kT), 0, st, p);
-        else if (label_kind == 1) hipLaunchKernelGGL((upsample_ce_bwd4_kernel<int, 24>), dim3((unsigned)grid4), dim3(kT), 0, st, p);
-        else hipLaunchKernelGGL((upsample_ce_bwd4_kernel<long long, 24>), dim3((unsigned)grid4), dim3(kT), 0, st, p);
-        return DP_LAUNCH_STATUS();
-    }
     p.tiles_y = (Hi + BT_H - 1) / BT_H; p.tiles_x = (Wi + BT_W - 1) / BT_W;
     const long grid = (long)N * p.tiles_y * p.tiles_x;
     if (grid > 0x7fffffffL) return -2;
