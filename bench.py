@@ -152,14 +152,19 @@ def main():
     engine = TrainEngine(model, criterion, lr=5e-8 if instance else 0.007, momentum=0.9, weight_decay=5e-4,
                          device=info.device, bucket_mb=args.bucket_mb)
     if args.batch <= 0:
-        # sized for the 288 GB of HBM3E: 984-986 img/s at 256 against 955-968 at 128 (profiles/r2_native_v38_b256_*);
-        # 384 buys nothing more.  Other models / the stock path keep 128 (their measured configurations).
+        # sized for the 288 GB of HBM3E: 1,037-1,041 img/s at 256 against 1,001 at 128; 320 / 384 / 512 give 1,047 /
+        # 1,041-1,059 / 1,034 (profiles/r3_bench_*): flat within the box-to-box spread.  The stock path keeps 128.
         if on_gpu and args.impl == "native" and args.model == "deeplabv3plus_resnet101" and not instance and args.crop == 513:
             args.batch = 256
+        elif "xception" in args.model and on_gpu and args.impl == "native":
+            args.batch = 128         # output stride 8: 310 img/s at 64, 318 at 96, 317 at 128 (184 GiB) since the
+            #                          weight-gradient stream no longer doubles the reserved memory (round 2: 234)
         elif "xception" in args.model:
-            args.batch = 64          # output stride 8: 305-314 img/s at 64, nothing more at 96, 234 at 128
+            args.batch = 64
+        elif instance and on_gpu and args.impl == "native":
+            args.batch = 64          # DANet 512x512: 366 img/s at 32, 382 at 64 (50 GiB)
         elif instance:
-            args.batch = 32          # DANet 512x512: 340-345 img/s (352 at 64, 356 at 96)
+            args.batch = 32
         else:
             args.batch = 128
     B, S = args.batch, args.crop

@@ -2,9 +2,10 @@
 from . import workspace  # noqa: F401
 from ._backend import (NativeLibraryMissing, backend, deterministic, deterministic_mode, get_backend,  # noqa: F401
                        lib_built, set_backend, set_deterministic, use_hip)
-from .augment import (IMAGENET_MEAN, IMAGENET_STD, affine_augment, affine_augment2, compose_crop,  # noqa: F401
-                      extreme_points, instance_augment, make_affine_params, make_warp_params, mask_bbox,
-                      nellipse_guidance_)
+from .augment import (IMAGENET_MEAN, IMAGENET_STD, affine_augment, affine_augment2, bbox_mask,  # noqa: F401
+                      compose_crop, confidence_map, dynamic_crop_relax, expand_bbox, extreme_points,
+                      extreme_points_heatmap, instance_augment, make_affine_params, make_warp_params, mask_bbox,
+                      nellipse_guidance_, paste_jaccard)
 from .batchnorm import (BatchNorm2d, batch_norm_act, convert_sync_batchnorm,  # noqa: F401
                         freeze_batchnorm)
 from .bnfold import conv_bn_add_relu  # noqa: F401

@@ -341,6 +341,117 @@ def nellipse_guidance_(out: torch.Tensor, pts: torch.Tensor, channel: int = 3, a
 
 
 @torch.no_grad()
+# ---- batched device forms of the transforms the reference's script does not call ------------------------------------
+# (`/root/reference/custom_transforms.py`: CreateBBMask :67-74, ExtremePoints :221-251, AddConfidenceMap :253-298,
+# CropFromMask :377-452.)  Tensor expressions over the whole batch on whatever device the masks live on — no per-sample
+# host loop, no host read; the extreme points and bounding boxes come from the kernels above.  Values follow
+# data/transforms.py (the CPU forms, which the tests compare against), quirks included.
+def _grid(h: int, w: int, device):
+    ys = torch.arange(h, device=device, dtype=torch.float32).view(1, h, 1)
+    xs = torch.arange(w, device=device, dtype=torch.float32).view(1, 1, w)
+    return ys, xs
+
+
+def _identity_bbox(mask_u8: torch.Tensor) -> torch.Tensor:
+    ident = torch.tensor([1.0, 0, 0, 0, 1, 0]).repeat(mask_u8.shape[0], 1)
+    return mask_bbox(mask_u8, ident.to(mask_u8.device), validated=True)
+
+
+@torch.no_grad()
+def bbox_mask(mask_u8: torch.Tensor) -> torch.Tensor:
+    """``CreateBBMask``: float32 [B,H,W], 255 outside the mask's bounding box and 0 inside (the box's last row and
+    column stay 255, as in the CPU form's half-open slices); all 255 for an empty mask."""
+    bb = _identity_bbox(mask_u8).float()                                   # x0, y0, x1, y1 (x1 < 0: empty)
+    ys, xs = _grid(mask_u8.shape[1], mask_u8.shape[2], mask_u8.device)
+    x0, y0, x1, y1 = (bb[:, i].view(-1, 1, 1) for i in range(4))
+    inside = (xs >= x0) & (xs < x1) & (ys >= y0) & (ys < y1)
+    return torch.where(inside, 0.0, 255.0)
+
+
+@torch.no_grad()
+def extreme_points_heatmap(mask_u8: torch.Tensor, sigma: float = 10.0, random: bool = False, seed: int = 0) -> torch.Tensor:
+    """``ExtremePoints`` (pert = 0): float32 [B,H,W], the maximum of four Gaussians
+    ``exp(-4 ln2 ((x-cx)^2 + (y-cy)^2) / sigma^2)`` at the left / right / top / bottom extreme pixel
+    (``helpers.make_gt``); zeros for an empty mask."""
+    pts = extreme_points(mask_u8, random, seed).to(mask_u8.device).float()  # [B,4,2] (x, y), -1 when empty
+    ys, xs = _grid(mask_u8.shape[1], mask_u8.shape[2], mask_u8.device)
+    cx, cy = pts[:, :, 0].view(-1, 4, 1, 1), pts[:, :, 1].view(-1, 4, 1, 1)
+    d2 = (xs.unsqueeze(1) - cx) ** 2 + (ys.unsqueeze(1) - cy) ** 2
+    heat = torch.exp(-4.0 * math.log(2.0) * d2 / float(sigma) ** 2).amax(dim=1)
+    empty = (pts[:, 0, 0] < 0).view(-1, 1, 1)
+    return torch.where(empty, torch.zeros_like(heat), heat)
+
+
+@torch.no_grad()
+def confidence_map(mask_u8: torch.Tensor, hm_type: str = "l1l2", tau: float = 1.0, random: bool = False,
+                   seed: int = 0) -> torch.Tensor:
+    """``AddConfidenceMap``'s extra channel: float32 [B,H,W] in 0..255, min-max normalised per sample.
+    ``l1l2``: exp(-(l1 + l2) / 2 tau) of the distances to the chords left-right and top-bottom of the extreme points,
+    each in units of the OTHER chord's half length (``generate_mvL1L2_image_skewed_axes``); ``gaussian``: the
+    multivariate Gaussian fitted to the mask pixels, covariance / 0.5 (``generate_mvgauss_image``; the CPU form
+    ignores ``tau`` for this type, so does this one).  Zeros when the mask is empty or full."""
+    bsz, h, w = mask_u8.shape
+    dev = mask_u8.device
+    m = (mask_u8 != 0)
+    ys, xs = _grid(h, w, dev)
+    cnt = m.flatten(1).sum(1).float()
+    if hm_type == "l1l2":
+        pts = extreme_points(mask_u8, random, seed).to(dev).float()
+
+        def dist(p, q):                                  # |cross(q - p, x - p)| / |q - p|, and |q - p|
+            d = q - p
+            n = torch.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2) + 1e-6
+            num = (d[:, 1].view(-1, 1, 1) * (xs - p[:, 0].view(-1, 1, 1))
+                   - d[:, 0].view(-1, 1, 1) * (ys - p[:, 1].view(-1, 1, 1))).abs()
+            return num / n.view(-1, 1, 1), n
+        d_lr, len_lr = dist(pts[:, 0], pts[:, 1])
+        d_tb, len_tb = dist(pts[:, 2], pts[:, 3])
+        d1 = d_lr / (0.5 * len_tb + 1e-6).view(-1, 1, 1)
+        d2 = d_tb / (0.5 * len_lr + 1e-6).view(-1, 1, 1)
+        hmap = torch.exp(-0.5 * (d1 + d2 + torch.sqrt(d1 ** 2 + d2 ** 2)) / max(float(tau), 1e-6))
+    elif hm_type == "gaussian":
+        mf = m.float()
+        n = cnt.clamp_min(1.0).view(-1, 1, 1)
+        mx, my = (mf * xs).sum((1, 2), keepdim=True) / n, (mf * ys).sum((1, 2), keepdim=True) / n
+        dx, dy = xs - mx, ys - my
+        nm1 = (cnt - 1.0).clamp_min(1.0).view(-1, 1, 1)                   # np.cov: unbiased
+        sxx = (mf * dx * dx).sum((1, 2), keepdim=True) / nm1 / 0.5 + 1e-3
+        syy = (mf * dy * dy).sum((1, 2), keepdim=True) / nm1 / 0.5 + 1e-3
+        sxy = (mf * dx * dy).sum((1, 2), keepdim=True) / nm1 / 0.5
+        det = sxx * syy - sxy * sxy
+        hmap = torch.exp(-0.5 * (syy * dx * dx - 2 * sxy * dx * dy + sxx * dy * dy) / det)
+        hmap = torch.where((cnt < 2).view(-1, 1, 1), torch.zeros_like(hmap), hmap)
+    else:
+        raise ValueError(f"unknown hm_type {hm_type}")
+    lo, hi = hmap.amin((1, 2), keepdim=True), hmap.amax((1, 2), keepdim=True)
+    out = (hmap - lo) / (hi - lo + 1e-10) * 255.0
+    trivial = ((cnt == 0) | (cnt == h * w)).view(-1, 1, 1)
+    return torch.where(trivial, torch.zeros_like(out), out)
+
+
+@torch.no_grad()
+def dynamic_crop_relax(bbox: torch.Tensor, d: int = 512, dz: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``CropFromMask``'s relax per sample (int32 [B]) from the inclusive mask boxes ``bbox`` [B,4]: the border that
+    makes the object take ``dz`` of the ``d`` x ``d`` input — ``ceil(max((d - side zoom) / (2 zoom), thresh))`` with
+    ``zoom = dz / side``.  ``dz``: [B] (training: drawn per call in [floor(sqrt(.45 d^2)), floor(sqrt(.6 d^2)))) or
+    None = validation's ``floor(sqrt(d^2 / 2))``.  Feed the result to ``expand_bbox`` + ``compose_crop(relax=0)``."""
+    dz0 = float(int(math.sqrt(d ** 2 * 0.5)))
+    thresh = ((d - dz0) * (d / 5)) / (2 * dz0)
+    bb = bbox.float()
+    side = torch.maximum(torch.maximum(bb[:, 2] - bb[:, 0], bb[:, 3] - bb[:, 1]), torch.ones_like(bb[:, 0]))
+    dzv = torch.full_like(side, dz0) if dz is None else dz.to(side.device).float()
+    zoom = dzv / side
+    relax = torch.clamp_min((d - side * zoom) / (2 * zoom), thresh)
+    return torch.ceil(relax).to(torch.int32)
+
+
+def expand_bbox(bbox: torch.Tensor, relax: torch.Tensor) -> torch.Tensor:
+    """Inclusive boxes grown by a per-sample border (empty boxes, x1 < x0, stay empty)."""
+    r = relax.to(bbox.device, torch.int32)
+    out = torch.stack([bbox[:, 0] - r, bbox[:, 1] - r, bbox[:, 2] + r, bbox[:, 3] + r], dim=1).to(torch.int32)
+    return torch.where((bbox[:, 2] < bbox[:, 0]).view(-1, 1), bbox.to(torch.int32), out)
+
+
 @torch.no_grad()
 def paste_jaccard(logits: torch.Tensor, crop_bbox: torch.Tensor, gt_u8: torch.Tensor, void_u8: Optional[torch.Tensor],
                   src_idx, sizes, relax: int = 50, thresholds=(0.3, 0.5, 0.8), validated: bool = False) -> torch.Tensor:

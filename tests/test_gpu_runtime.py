@@ -178,6 +178,30 @@ def test_entrypoint_validates_on_the_device(task, tmp_path):
         assert abs(vals["auto"]["mIoU"] - vals["cpu"]["mIoU"]) < 5e-3, vals
 
 
+def test_device_forms_of_the_unused_transforms_on_the_gpu():
+    """ops.bbox_mask / extreme_points_heatmap / confidence_map / dynamic_crop_relax on device masks (bounding boxes and
+    extreme points from the HIP kernels) equal the same functions on CPU tensors, which tests/test_runtime.py checks
+    against data/transforms.py (CreateBBMask, ExtremePoints, AddConfidenceMap, CropFromMask)."""
+    from distributedpytorch_amd import ops
+    g = torch.Generator().manual_seed(7)
+    masks = torch.zeros(6, 90, 120, dtype=torch.uint8)
+    yy, xx = torch.meshgrid(torch.arange(90), torch.arange(120), indexing="ij")
+    for b in range(5):
+        cy, cx = int(torch.randint(20, 70, (1,), generator=g)), int(torch.randint(30, 90, (1,), generator=g))
+        ry, rx = int(torch.randint(6, 20, (1,), generator=g)), int(torch.randint(8, 30, (1,), generator=g))
+        masks[b] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1).to(torch.uint8)
+    dm = masks.cuda()
+    assert torch.equal(ops.bbox_mask(dm).cpu(), ops.bbox_mask(masks))
+    assert torch.allclose(ops.extreme_points_heatmap(dm).cpu(), ops.extreme_points_heatmap(masks), atol=1e-5)
+    for kind in ("l1l2", "gaussian"):
+        a, b = ops.confidence_map(dm, kind).cpu(), ops.confidence_map(masks, kind)
+        assert torch.allclose(a, b, atol=0.05), (kind, float((a - b).abs().max()))
+    bd, bc = ops.augment._identity_bbox(dm), ops.augment._identity_bbox(masks)
+    assert torch.equal(bd.cpu(), bc)
+    assert torch.equal(ops.dynamic_crop_relax(bd).cpu(), ops.dynamic_crop_relax(bc))
+    assert torch.equal(ops.expand_bbox(bd, ops.dynamic_crop_relax(bd)).cpu(), ops.expand_bbox(bc, ops.dynamic_crop_relax(bc)))
+
+
 def test_gpu_batch_loader_feeds_engine():
     """train_pascal's GPU data path: device sample store -> gather -> TrainEngine (both tasks)."""
     from distributedpytorch_amd.data import SyntheticVOC
