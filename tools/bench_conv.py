@@ -56,6 +56,18 @@ R101_DEEPLAB = [
 ]
 
 
+# Xception-65 OS8 (728-wide flows stored 768 wide): the pointwise halves of the separable units
+X65_OS8 = [
+    ("entry.pw128", 2, 128, 128, 257, 1, 1, 0, 1),
+    ("entry.pw256", 2, 256, 256, 129, 1, 1, 0, 1),
+    ("mid.pw768", 52, 768, 768, 65, 1, 1, 0, 1),
+    ("exit.pw1024", 1, 768, 1024, 65, 1, 1, 0, 1),
+    ("exit.pw1536", 2, 1536, 1536, 65, 1, 1, 0, 1),
+    ("exit.pw2048", 1, 1536, 2048, 65, 1, 1, 0, 1),
+]
+LAYERS = {"r101": R101_DEEPLAB, "x65": X65_OS8}
+
+
 def timeit(fn, iters=5, warm=2, inner=10):
     """Median µs per call; ``inner`` calls are queued back to back between the two events so the
     host-side launch cost of one call hides behind the previous kernel."""
@@ -84,7 +96,7 @@ def sweep(args):
     tot_f = {c: 0.0 for c in cfgs}
     tot_d = {c: 0.0 for c in cfgs}
     best_f = best_d = 0.0
-    for name, cnt, cin, cout, hw, k, stride, pad, dil in R101_DEEPLAB:
+    for name, cnt, cin, cout, hw, k, stride, pad, dil in LAYERS[args.net]:
         if (args.filter and args.filter not in name) or k == 7:
             continue
         n = args.batch
@@ -119,7 +131,7 @@ def sweep_wgrad(args):
     dev = "cuda"
     print(f"{'layer':16s} {'cnt':>3s} {'P':>7s} {'Cout':>5s} {'RSC':>6s} | " + " ".join(f"s{c:<6d}" for c in splits))
     tot = {c: 0.0 for c in splits}
-    for name, cnt, cin, cout, hw, k, stride, pad, dil in R101_DEEPLAB:
+    for name, cnt, cin, cout, hw, k, stride, pad, dil in LAYERS[args.net]:
         if args.filter and args.filter not in name:
             continue
         n = args.batch
@@ -138,20 +150,70 @@ def sweep_wgrad(args):
     print("TOTAL ms" + " " * 35 + " ".join(f"{tot[c] / 1e3:7.2f}" for c in splits))
 
 
+def lib_gemm(args):
+    """1x1 stride-1 layers: [M, K] x [K, N] in bf16.  Forward with the statistics epilogue the step uses, the data
+    gradient plain, the weight gradient into an fp32 [N, K] — against torch.matmul on the same 2-D views."""
+    dev = "cuda"
+    print(f"{'layer':16s} {'cnt':>3s} {'M':>8s} {'N':>5s} {'K':>5s} | {'fwd':>7s} {'lib':>7s} {'TF':>5s} {'libTF':>5s} | "
+          f"{'dgrad':>7s} {'lib':>7s} {'TF':>5s} {'libTF':>5s} | {'wgrad':>7s} {'lib':>7s} {'TF':>5s} {'libTF':>5s}")
+    tot = [0.0] * 6
+    for name, cnt, cin, cout, hw, k, stride, pad, dil in LAYERS[args.net]:
+        if (args.filter and args.filter not in name) or k != 1 or stride != 1 or cin % 8 or cout % 8:
+            continue
+        n = args.batch
+        m = n * hw * hw
+        x = torch.randn(n, cin, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5).to(torch.bfloat16) \
+            .contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(n, cout, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wt = _hip_conv.weight_transpose(w)
+        stats = torch.zeros(_hip_conv.stat_replicas(m), 2, cout, device=dev)
+        out = torch.zeros(cout, cin, 1, 1, device=dev).contiguous(memory_format=torch.channels_last)
+        x2, dy2, w2 = x.permute(0, 2, 3, 1).reshape(m, cin), dy.permute(0, 2, 3, 1).reshape(m, cout), w.view(cout, cin)
+        w2t, dy2t = w2.t().contiguous(), dy2.t()
+        gf = 2.0 * m * cin * cout / 1e9
+        t = [timeit(lambda: _hip_conv.igemm(x, w, (hw, hw), 1, 1, (0, 0), (1, 1), None, stats)),
+             timeit(lambda: torch.matmul(x2, w2t)),
+             timeit(lambda: _hip_conv.igemm(dy, wt, (hw, hw), 1, 1, (0, 0), (1, 1))),
+             timeit(lambda: torch.matmul(dy2, w2)),
+             timeit(lambda: _hip_conv.wgrad(dy, x, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=out)),
+             timeit(lambda: torch.matmul(dy2t, x2))]
+        for i in range(6):
+            tot[i] += cnt * t[i]
+        print(f"{name:16s} {cnt:3d} {m:8d} {cout:5d} {cin:5d} | " + " | ".join(
+            f"{t[i]:7.1f} {t[i + 1]:7.1f} {gf / t[i] * 1e3:5.0f} {gf / t[i + 1] * 1e3:5.0f}" for i in (0, 2, 4)), flush=True)
+        del x, dy, x2, dy2
+    print("TOTAL weighted ms: " + "  ".join(f"{nm} {tot[i] / 1e3:.2f} lib {tot[i + 1] / 1e3:.2f}"
+                                             for nm, i in (("fwd", 0), ("dgrad", 2), ("wgrad", 4))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--stock", action="store_true", help="also time MIOpen through F.conv2d")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--net", default="r101", choices=sorted(LAYERS))
     ap.add_argument("--splits", default="", help="comma list of wgrad split-K counts to sweep (0 = auto)")
     ap.add_argument("--cfgs", default="", help="comma list of conv_igemm2 tile configs to sweep (0 = gen-1 kernel)")
+    ap.add_argument("--lib-gemm", action="store_true",
+                    help="yardstick: the 1x1 stride-1 layers as plain GEMMs through torch.matmul (hipBLASLt), same "
+                         "operands, next to the hand-written kernels (which also carry the fused epilogues)")
     args = ap.parse_args()
+    if args.cfgs:
+        sweep(args)
+        return
+    if args.splits:
+        sweep_wgrad(args)
+        return
+    if args.lib_gemm:
+        lib_gemm(args)
+        return
     dev = "cuda"
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "sfwd": 0.0, "sbwd": 0.0}
     tot_fl = 0.0
     print(f"{'layer':16s} {'cnt':>3s} {'GF':>7s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | "
           f"{'wgrad us':>8s} {'TF':>6s}" + (" | stock fwd  bwd(us)" if args.stock else ""))
-    for name, cnt, cin, cout, hw, k, stride, pad, dil in R101_DEEPLAB:
+    for name, cnt, cin, cout, hw, k, stride, pad, dil in LAYERS[args.net]:
         if args.filter and args.filter not in name:
             continue
         n = args.batch
@@ -186,12 +248,6 @@ def main():
             tot["sbwd"] += cnt * t_sb
             line += f" | {t_sf:8.1f} {t_sb:8.1f}"
         print(line, flush=True)
-    if args.cfgs:
-        sweep(args)
-        return
-    if args.splits:
-        sweep_wgrad(args)
-        return
     print(f"TOTAL weighted: fwd {tot['fwd'] / 1e3:.2f} ms ({tot_fl / tot['fwd'] * 1e3:.0f} TF)  "
           f"dgrad {tot['dgrad'] / 1e3:.2f} ms ({tot_fl / tot['dgrad'] * 1e3:.0f} TF)  "
           f"wgrad {tot['wgrad'] / 1e3:.2f} ms ({tot_fl / tot['wgrad'] * 1e3:.0f} TF)  [{tot_fl / 1e3:.2f} TFLOP per pass]")

@@ -66,6 +66,8 @@ def run(impl, args):
     ops.set_backend("torch" if impl.startswith("stock") else "auto")
     dev = torch.device("cuda")
     torch.manual_seed(args.seed)
+    from distributedpytorch_amd.ops import batchnorm as _bn
+    _bn._drop_calls = 0                  # the dropout masks are a function of (seed, rank, call count): every run from 0
     model = build_model(args.model, 21, **({"output_stride": args.output_stride} if args.output_stride else {}))
     if args.no_dropout:
         for m in model.modules():
