@@ -178,10 +178,12 @@ def lib_gemm(args):
              timeit(lambda: torch.matmul(dy2, w2)),
              timeit(lambda: _hip_conv.wgrad(dy, x, (cout, cin, 1, 1), (1, 1), (0, 0), (1, 1), out=out)),
              timeit(lambda: torch.matmul(dy2t, x2))]
+        t_plain = timeit(lambda: _hip_conv.igemm(x, w, (hw, hw), 1, 1, (0, 0), (1, 1)))
         for i in range(6):
             tot[i] += cnt * t[i]
         print(f"{name:16s} {cnt:3d} {m:8d} {cout:5d} {cin:5d} | " + " | ".join(
-            f"{t[i]:7.1f} {t[i + 1]:7.1f} {gf / t[i] * 1e3:5.0f} {gf / t[i + 1] * 1e3:5.0f}" for i in (0, 2, 4)), flush=True)
+            f"{t[i]:7.1f} {t[i + 1]:7.1f} {gf / t[i] * 1e3:5.0f} {gf / t[i + 1] * 1e3:5.0f}" for i in (0, 2, 4))
+              + f" | fwd without the statistics epilogue {t_plain:7.1f}", flush=True)
         del x, dy, x2, dy2
     print("TOTAL weighted ms: " + "  ".join(f"{nm} {tot[i] / 1e3:.2f} lib {tot[i + 1] / 1e3:.2f}"
                                              for nm, i in (("fwd", 0), ("dgrad", 2), ("wgrad", 4))))
