@@ -283,16 +283,33 @@ def compose_crop(mats: torch.Tensor, bbox: torch.Tensor, out_size: Tuple[int, in
     return om, oc, ob
 
 
+_IDENT: dict = {}
+
+
+def _identity_mats(n: int, device) -> torch.Tensor:
+    """[n, 6] identity affine rows ON ``device``, built once per (n, device): a host tensor moved with ``.to(device)``
+    is a blocking copy from pageable memory — it waits for everything queued on the stream, i.e. one full host-device
+    synchronisation per batch in the instance task's loader (found as 100 ms of "data wait" per step behind a loader
+    whose own host cost is 1 ms, tools/loader_host_cost.py)."""
+    key = (int(n), str(device))
+    t = _IDENT.get(key)
+    if t is None:
+        t = torch.zeros(n, 6, dtype=torch.float32, device=device)
+        t[:, 0] = 1.0
+        t[:, 4] = 1.0
+        _IDENT[key] = t
+    return t
+
+
 @torch.no_grad()
 def extreme_points(mask_u8: torch.Tensor, random: bool = True, seed: int = 0) -> torch.Tensor:
     """int32 [B,4,2] (x, y) of the left / right / top / bottom extreme pixel of each mask [B,H,W]; among the mask
     pixels on the extreme line one is drawn at random (training) or the median one taken (validation) —
     ``helpers.extreme_points`` / ``extreme_points_fixed`` with ``pert=0`` (`/root/reference/custom_transforms.py:40-42`).
     Empty masks give −1."""
-    ident = torch.tensor([1.0, 0, 0, 0, 1, 0]).repeat(mask_u8.shape[0], 1)
     if B.use_hip(mask_u8):
         from . import _hip_misc
-        bbox = _hip_misc.mask_bbox(mask_u8, None, None, ident.to(mask_u8.device))
+        bbox = _hip_misc.mask_bbox(mask_u8, None, None, _identity_mats(mask_u8.shape[0], mask_u8.device))
         return _hip_misc.extreme_points(mask_u8, bbox, random, seed)
     Bn, H, W = mask_u8.shape
     pts = torch.full((Bn, 4, 2), -1, dtype=torch.int32)
@@ -353,8 +370,7 @@ def _grid(h: int, w: int, device):
 
 
 def _identity_bbox(mask_u8: torch.Tensor) -> torch.Tensor:
-    ident = torch.tensor([1.0, 0, 0, 0, 1, 0]).repeat(mask_u8.shape[0], 1)
-    return mask_bbox(mask_u8, ident.to(mask_u8.device), validated=True)
+    return mask_bbox(mask_u8, _identity_mats(mask_u8.shape[0], mask_u8.device), validated=True)
 
 
 @torch.no_grad()

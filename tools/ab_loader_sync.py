@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""A/B on one box: bench.py with a full device synchronisation put back into the instance loader (what the blocking
+identity-matrix copy did until round 3) against the loader as it is.  `python tools/ab_loader_sync.py sync|nosync <bench args>`"""
+import os
+import runpy
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+mode = sys.argv[1]
+if mode == "sync":
+    import distributedpytorch_amd.ops.augment as aug
+    orig = aug._identity_mats
+
+    def synced(n, device):
+        torch.cuda.synchronize()
+        return orig(n, device)
+    aug._identity_mats = synced
+sys.argv = ["bench.py"] + sys.argv[2:]
+runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")

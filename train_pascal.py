@@ -228,6 +228,11 @@ def train_epoch(engine, loader, scheduler, epoch, args, log, guard=None, checker
     n_iter, n_img = 0, 0
     t0 = timeit.default_timer()
     data_wait, t_fetch = 0.0, timeit.default_timer()
+    # `data_wait` is host wall time inside the loader: real starvation on the CPU path, but on the device path (1 ms of
+    # host work per batch, tools/loader_host_cost.py) mostly the launch queue pushing back on a host that is a step
+    # ahead.  `busy` tells the two apart: the share of fetches that BEGAN with the step's stream still working.
+    stream = torch.cuda.current_stream(engine.device) if engine.on_gpu else None
+    busy = 0
     for ii, (inputs, gts) in enumerate(loader):
         data_wait += timeit.default_timer() - t_fetch          # host time blocked on the data path
         if args.max_iters and ii >= args.max_iters:
@@ -246,10 +251,13 @@ def train_epoch(engine, loader, scheduler, epoch, args, log, guard=None, checker
             extra = {}
             if engine.on_gpu:
                 extra["hbm_peak_gib"] = torch.cuda.max_memory_allocated(engine.device) / 2 ** 30
+                extra["gpu_busy_at_fetch"] = busy / max(ii, 1)
             log.log("train", epoch=epoch, iter=ii + 1, loss=float(running) / n_iter,
                     lr=engine.optimizer.param_groups[0]["lr"],
                     img_per_s=n_img * dist_env.get_world_size() / dt,
                     data_wait_ms=1e3 * data_wait / n_iter, **extra, **engine.timer.summary())
+        if stream is not None and not stream.query():
+            busy += 1
         t_fetch = timeit.default_timer()
     if guard is not None:
         guard.check(engine.global_step)
