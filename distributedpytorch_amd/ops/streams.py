@@ -31,12 +31,19 @@ _ENABLED = os.environ.get("DPAMD_AUX_STREAM", "1") != "0"
 # drained, a kernel of another stream can.  Measured at B32 (gpurun_out/s8_bench_b32_aux*.log): 697 img/s
 # with one aux stream, 685 with two, so one is the default; GPU_MAX_HW_QUEUES is 4 (main + comm + 2 aux).
 _NAUX = 1
-# Queue priority of the auxiliary stream(s).  "low": created with hipStreamCreateWithPriority at the LEAST
-# priority of the device's range, so when both hardware queues hold ready workgroups the dgrad -> BN-backward
-# chain (the critical path, on the normal-priority current stream) is dispatched first and the weight
-# gradients fill the CUs it leaves free instead of taking half of them.  torch.cuda.Stream only reaches the
-# normal and high levels, hence the direct runtime call + torch.cuda.ExternalStream.
-_PRIORITY = "low"
+# Queue priority of the auxiliary stream(s).  "normal" (default): a stream of PyTorch's pool.  "low": created with
+# hipStreamCreateWithPriority at the LEAST priority of the device's range (torch.cuda.Stream only reaches the normal
+# and high levels, hence the direct runtime call + torch.cuda.ExternalStream), so that when both hardware queues hold
+# ready workgroups the dgrad -> BN-backward chain is dispatched first.  Low was the default of rounds 1-3 (+0.7 % at
+# B128 in round 1; 0.0 / +0.3 / +0.9 % on R101 / Xception-65 / DANet at the end of round 3, same-box A/B) until a
+# reproducible STALL was found with it: in a process that had created several other streams (device sample stores'
+# copy streams), a ResNet-18 step stopped with the step's stream waiting at join() for the low-priority queue, which
+# made no progress for minutes; the same sequence with this stream at normal priority (pool stream, or the same raw
+# handle path at priority 0) completes, and so does the low-priority run with serialised launches
+# (profiles/r3_low_priority_stream_stall.md).  No ordering cycle exists between the two streams (every wait
+# refers to work enqueued earlier), so the queue is starved below the runtime; a fraction of a percent is not worth
+# a job that can stop.  set_priority("low") remains for experiments.
+_PRIORITY = "normal"
 _raw_handles: list = []     # keeps the hipStream_t of the external streams (never destroyed: process lifetime)
 
 
@@ -75,10 +82,10 @@ def set_enabled(flag: bool) -> None:
 
 
 def set_priority(level: str) -> None:
-    """'low' (default) | 'normal'.  Streams that exist already are joined and dropped; the next fork creates new
+    """'normal' (default) | 'low'.  Streams that exist already are joined and dropped; the next fork creates new
     ones.  parallel.p2p calls this with 'normal' when ranks SHARE a device (rehearsals): a peer's spinning one-shot
-    all-reduce kernel on a normal-priority queue outranks this rank's low-priority weight gradients, which the
-    matching all-reduce of this rank waits for — both then sit until the bounded spin times out."""
+    all-reduce kernel on a normal-priority queue outranks low-priority weight gradients, which the matching
+    all-reduce of this rank waits for — both then sit until the bounded spin times out."""
     global _PRIORITY
     if level not in ("low", "normal"):
         raise ValueError("aux stream priority: 'low' or 'normal'")

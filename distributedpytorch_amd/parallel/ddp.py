@@ -20,7 +20,7 @@ whose gradients exist only when backward ends) is kept small (``tail_bytes``): i
 the only one nothing can hide.
 
 Launch choreography on the GPU: the gradients of a bucket are written by kernels of two streams —
-weight gradients on the low-priority auxiliary stream (``ops.streams``), BN affine gradients on the
+weight gradients on the auxiliary stream (``ops.streams``), BN affine gradients on the
 step's own stream.  A bucket's collective is issued from a dedicated COMM-LAUNCH stream that waits
 on an event recorded on the step's stream and on the auxiliary stream(s) at the moment the
 bucket's last gradient kernel was enqueued; the step's stream itself never waits for the weight

@@ -65,18 +65,13 @@ class TrainEngine:
         self.timer = PhaseTimer(self.on_gpu, markers)
         self.global_step = 0
         self._step_events: list = []      # bounds how far the host may run ahead of the GPU
-        # The weight gradients run on a LOW-priority stream (ops.streams): when both hardware queues hold ready
-        # workgroups the forward / dgrad -> BN-backward chain is dispatched first.  Measured at B128
-        # (gpurun_out/s94, s95): 951 img/s with equal priorities, 957-958 with the low-priority auxiliary stream.
-        # Running the step itself on a HIGH-priority stream gave 961-962 on one GPU; not built in: RCCL's kernels run
-        # at normal priority and would be dispatched behind every compute kernel, and two ranks SHARING one GPU (the
-        # rehearsal of tests/test_gpu_p2p.py) stalled with it.
-        # Why it stalls shared-GPU ranks (round-1 ADVICE): the one-shot SyncBN kernel (csrc/p2p_allreduce.hip) SPINS
-        # until every peer's granules arrive.  On a high-priority queue the spinning kernel of rank A outranks the
-        # (normal-priority, or equally high but later) kernel of rank B that would produce those granules when both
-        # share a device, so nothing progresses until the bounded spin times out — and a timed-out reduction returns
-        # partial sums.  High priority is therefore refused whenever peers exist (world > 1): the step's kernels and
-        # the collectives they wait on must be dispatched at the same level.
+        # Stream priorities (history; ops/streams.py has the current state): a LOW-priority weight-gradient stream
+        # was worth 951 -> 957-958 img/s at B128 in round 1 and nothing measurable on R101 at the end of round 3, and
+        # stalled a step in a process with several other streams — every stream runs at normal priority now.  A
+        # HIGH-priority step stream (961-962) was never built in: RCCL's kernels run at normal priority and would be
+        # dispatched behind every compute kernel, and the one-shot SyncBN kernel (csrc/p2p_allreduce.hip) SPINS until
+        # every peer's granules arrive — on a queue that outranks the producer of those granules (ranks sharing a
+        # device) nothing progresses until the bounded spin times out.
     # ------------------------------------------------------------------
     def prepare_input(self, images: torch.Tensor) -> torch.Tensor:
         x = images.to(self.device, non_blocking=True)

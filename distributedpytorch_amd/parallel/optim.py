@@ -68,11 +68,11 @@ class FlatSGD:
 
     def state_dict(self) -> Dict:
         """Momentum PER PARAMETER in the architecture's shapes (not the arena's flat, possibly padded layout)."""
+        from ..utils.hostcopy import to_host
         m = self.arena.flat_m.detach()
-        by_name = {}
-        for s in self.arena.slots:
-            t = _view_like(m, s.offset, s.param)              # logical shape (4-D weights lie KRSC in the arena)
-            by_name[s.name] = self._adapt(s.name, t, True).cpu().contiguous().clone()
+        # logical shapes (4-D weights lie KRSC in the arena); one device->host copy for all of them
+        host = to_host([self._adapt(s.name, _view_like(m, s.offset, s.param), True) for s in self.arena.slots])
+        by_name = {s.name: t for s, t in zip(self.arena.slots, host)}
         return {"format": 2, "momentum_by_name": by_name, "steps": self._steps,
                 "lrs": [pg["lr"] for pg in self.param_groups]}
 

@@ -29,13 +29,10 @@ def _unwrap(model: nn.Module) -> nn.Module:
 
 def reference_state_dict(model: nn.Module) -> "OrderedDict[str, torch.Tensor]":
     """``module.``-prefixed, fp32/int64, contiguous, CPU tensors."""
-    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for k, v in _unwrap(model).state_dict().items():
-        t = v.detach()
-        if t.is_floating_point():
-            t = t.float()
-        out[PREFIX + k] = t.cpu().contiguous().clone()
-    return out
+    from .hostcopy import to_host
+    items = list(_unwrap(model).state_dict().items())
+    host = to_host([v.detach().float() if v.is_floating_point() else v.detach() for _, v in items])
+    return OrderedDict((PREFIX + k, t) for (k, _), t in zip(items, host))
 
 
 def strip_prefix(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":

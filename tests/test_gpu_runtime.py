@@ -202,6 +202,45 @@ def test_device_forms_of_the_unused_transforms_on_the_gpu():
     assert torch.equal(ops.expand_bbox(bd, ops.dynamic_crop_relax(bd)).cpu(), ops.expand_bbox(bc, ops.dynamic_crop_relax(bc)))
 
 
+def test_checkpoint_host_copies_are_batched_and_exact():
+    """utils.hostcopy: the checkpoint's tensors leave the device in one copy per dtype (1,021 blocking copies per R101
+    checkpoint before) — values, shapes and contiguity as `.cpu().contiguous()` gives them, storages independent;
+    Xception's padded flow still saves in its logical 728-wide shapes."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine
+    from distributedpytorch_amd.utils.checkpoint import reference_state_dict
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    model = build_model("deeplabv3plus_xception", 21, output_stride=16)
+    eng = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.01, momentum=0.9, device=dev)
+    x = torch.randn(2, 3, 97, 97, device=dev).to(eng.compute_dtype).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 21, (2, 97, 97), device=dev, dtype=torch.uint8)
+    eng.train_step(x, y)
+    sd = reference_state_dict(eng.ddp)
+    ref = {"module." + k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu().contiguous()
+           for k, v in eng.ddp.module.state_dict().items()}
+    assert list(sd) == list(ref)
+    ptrs = set()
+    for k in ref:
+        assert sd[k].device.type == "cpu" and sd[k].is_contiguous() and sd[k].shape == ref[k].shape, k
+        assert sd[k].dtype == ref[k].dtype and torch.equal(sd[k], ref[k]), k
+        ptrs.add(sd[k].untyped_storage().data_ptr())
+    assert len(ptrs) == sum(1 for v in ref.values() if v.numel())
+    assert max(v.shape[0] for k, v in sd.items() if ".middle." in k and v.dim() == 4) == 728       # logical widths
+    mom = eng.optimizer.state_dict()["momentum_by_name"]
+    assert any(float(v.abs().max()) > 0 for v in mom.values())
+    for s in eng.optimizer.arena.slots:
+        assert mom[s.name].device.type == "cpu" and mom[s.name].is_contiguous()
+    eng2 = TrainEngine(build_model("deeplabv3plus_xception", 21, output_stride=16), SoftmaxCrossEntropy(255), lr=0.01,
+                       momentum=0.9, device=dev)
+    eng2.optimizer.load_state_dict(eng.optimizer.state_dict())
+    mom2 = eng2.optimizer.state_dict()["momentum_by_name"]
+    assert list(mom2) == list(mom) and all(torch.equal(mom2[k], mom[k]) for k in mom)
+    differ = int((eng2.optimizer.arena.flat_m != eng.optimizer.arena.flat_m).sum())
+    print("arena positions that differ after the round trip (padding channels only):", differ)
+
+
 def test_gpu_batch_loader_feeds_engine():
     """train_pascal's GPU data path: device sample store -> gather -> TrainEngine (both tasks)."""
     from distributedpytorch_amd.data import SyntheticVOC
