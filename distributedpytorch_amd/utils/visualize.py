@@ -46,7 +46,7 @@ def save_validation_panels(path: str, image_chw, gt_hw, outputs: Sequence, epoch
                 panels.append(o.argmax(0).astype(np.float32) if o.ndim == 3 else o)
             else:
                 o = o[0] if o.ndim == 3 else o
-                panels.append(1.0 / (1.0 + np.exp(-o)) if k == 0 else o)
+                panels.append(1.0 / (1.0 + np.exp(-np.clip(o, -60.0, 60.0))) if k == 0 else o)
         else:
             panels.append(None)
     fig = plt.figure(figsize=(16, 4.4))
