@@ -229,19 +229,76 @@ _AUTOTUNE = os.environ.get("DPAMD_CONV_AUTOTUNE", "1") != "0"
 # tuning run ever picked (32-wide-K 4-stage rings 11/12, 8-wave small-LDS 17/18, 2, 6) were removed in round 3;
 # 13 stays for the stem (profiles/r1_conv_cfg_sweep_b128.log has the sweep).
 _CANDIDATES = (1, 8, 9, 3, 10, 4, 5, 7, 14, 15, 16, 0)
-_TUNED: dict = {}
-_TUNE_COUNTS = {"packaged": 0, "measured_here": 0, "timed_on_this_rank": 0}
+_COLLECTIVE = 0          # > 0 inside collective_tuning(): every rank is known to meet the same problems in the same order
+
+
+class collective_tuning:
+    """Section in which ALL ranks run the same launches in the same order (a training step: same model, same per-rank
+    batch) — the only place where a tile choice may cost a collective.  Anywhere else a rank may be alone with a
+    problem (the master's validation figure, a validation tail batch of its own size): a broadcast there waits for
+    peers that never come.  Found by the 2-rank run of the entrypoint's flag matrix: rank 0 sat in the broadcast of
+    ``_agreed`` inside the master-only figure forward, rank 1 in the checkpoint barrier
+    (tools/gpu_runs/gpu_round3_r4y.sh)."""
+
+    def __enter__(self):
+        global _COLLECTIVE
+        _COLLECTIVE += 1
+
+    def __exit__(self, *exc):
+        global _COLLECTIVE
+        _COLLECTIVE -= 1
+        return False
+
+
+def _shared_choices() -> bool:
+    """May a choice made now go into (and be read from) the table every rank holds identically?"""
+    if _COLLECTIVE > 0:
+        return True
+    from ..parallel import dist_env
+    return dist_env.get_world_size() <= 1
+
+
+class _TuneTable(dict):
+    """Tile choices.  The dict itself holds what is IDENTICAL on every rank: the packaged table, a tune file, choices
+    agreed inside ``collective_tuning``.  ``local`` holds what this rank measured on its own outside such a section
+    (several ranks only); collective sections neither read nor write it — otherwise a rank that met a problem alone
+    earlier would skip the broadcast its peers enter for the same problem later."""
+
+    def __init__(self):
+        super().__init__()
+        self.local: dict = {}
+
+    def get(self, key, default=None):
+        v = dict.get(self, key)
+        if v is None and not _shared_choices():
+            v = self.local.get(key)
+        return default if v is None else v
+
+    def __setitem__(self, key, val):
+        if _shared_choices():
+            dict.__setitem__(self, key, val)
+        else:
+            self.local[key] = val
+
+
+_TUNED = _TuneTable()
+_TUNE_COUNTS = {"packaged": 0, "measured_here": 0, "timed_on_this_rank": 0, "timed_outside_collective_sections": 0}
 
 
 def _agreed(measure) -> int:
-    """The choice for a problem that is in no table.  One process: ``measure()``.  Several ranks: rank 0 measures
-    and everybody runs ITS choice (one small broadcast per new problem; every rank meets the same problems in the
-    same order: same model, same per-rank batch) — per-rank timing noise flips near-ties (20 of 101 problems
-    between two runs of one box), and under data parallelism the slowest rank's pick gates every step."""
+    """The choice for a problem that is in no table.  One process: ``measure()``.  Several ranks inside a
+    ``collective_tuning`` section: rank 0 measures and everybody runs ITS choice (one small broadcast per new
+    problem) — per-rank timing noise flips near-ties (20 of 101 problems between two runs of one box), and under data
+    parallelism the slowest rank's pick gates every step.  Several ranks outside such a section: this rank measures
+    for itself, no collective."""
     from ..parallel import dist_env
     _TUNE_COUNTS["measured_here"] += 1
     if dist_env.get_world_size() <= 1:
         _TUNE_COUNTS["timed_on_this_rank"] += 1
+        return int(measure())
+    if _COLLECTIVE <= 0:
+        _TUNE_COUNTS["timed_on_this_rank"] += 1
+        _TUNE_COUNTS["timed_outside_collective_sections"] += 1
         return int(measure())
     val = 0
     if dist_env.is_master():

@@ -94,17 +94,21 @@ class TrainEngine:
             if len(self._step_events) >= 2:
                 self._step_events.pop(0).synchronize()
         workspace.begin_step(self.device)   # one memset re-arms every reduction accumulator of the step
-        with self.timer.phase("fwd"):
-            out = self.ddp(x)
-            loss = self.criterion(out, y)
-            if self.accum_steps > 1:
-                loss = loss / self.accum_steps
-        with self.timer.phase("bwd"):
-            if last_micro:
-                loss.backward()
-            else:
-                with self.ddp.no_sync():
+        # forward + backward of a training step: the one place where every rank runs the same launches in the same
+        # order, hence the only place where a new problem's tile choice may be a collective (rank 0 measures)
+        from ..ops import _hip_conv
+        with _hip_conv.collective_tuning():
+            with self.timer.phase("fwd"):
+                out = self.ddp(x)
+                loss = self.criterion(out, y)
+                if self.accum_steps > 1:
+                    loss = loss / self.accum_steps
+            with self.timer.phase("bwd"):
+                if last_micro:
                     loss.backward()
+                else:
+                    with self.ddp.no_sync():
+                        loss.backward()
         self._micro += 1
         if last_micro:
             with self.timer.phase("comm_wait"):

@@ -321,8 +321,11 @@ def test_debug_mode_consistency_checks():
 
 
 def _tile_choice_agreed(rank, world, tmp):
-    """ops._hip_conv._agreed: a problem outside the packaged table is timed by rank 0 only and its choice is
-    broadcast — every rank ends with the same table (VERDICT r2 weak #3a)."""
+    """ops._hip_conv._agreed: inside a collective section (a training step) a problem outside the packaged table is
+    timed by rank 0 only and its choice is broadcast — every rank ends with the same table (VERDICT r2 weak #3a).
+    Outside such a section a rank may be alone with a problem (the master's validation figure, its own validation
+    tail batch): it decides for itself WITHOUT a collective, and that choice stays out of the shared table — a rank
+    that met a problem alone must still enter the broadcast its peers enter for the same problem in a later step."""
     from distributedpytorch_amd.ops import _hip_conv
     calls = []
 
@@ -331,12 +334,29 @@ def _tile_choice_agreed(rank, world, tmp):
             calls.append(v)
             return v + 10 * rank            # a rank that timed for itself would disagree
         return f
-    _hip_conv._TUNE_COUNTS.update(measured_here=0, timed_on_this_rank=0)
-    got = [_hip_conv._agreed(measure(v)) for v in (3, 7, 0)]
+    _hip_conv._TUNE_COUNTS.update(measured_here=0, timed_on_this_rank=0, timed_outside_collective_sections=0)
+    with _hip_conv.collective_tuning():
+        got = [_hip_conv._agreed(measure(v)) for v in (3, 7, 0)]
     assert got == [3, 7, 0], (rank, got)
     assert calls == ([3, 7, 0] if rank == 0 else []), (rank, calls)
     rep = _hip_conv.tune_report()
     assert rep["measured_here"] == 3 and rep["timed_on_this_rank"] == (3 if rank == 0 else 0)
+    # ---- rank 0 alone with a problem (no peer calls anything): must return at once, with its own choice
+    table = _hip_conv._TUNED
+    key = ("test-only-problem", 1, 2, 3)
+    if rank == 0:
+        assert table.get(key) is None
+        table[key] = _hip_conv._agreed(measure(5))
+        assert table.get(key) == 5 and key not in table            # readable outside sections, not in the shared tier
+        assert _hip_conv.tune_report()["timed_outside_collective_sections"] == 1
+    # ---- the same problem arrives in a training step on every rank: everybody (rank 0 included) enters the broadcast
+    with _hip_conv.collective_tuning():
+        assert table.get(key) is None, rank
+        table[key] = _hip_conv._agreed(measure(9))
+        assert table.get(key) == 9 and dict.get(table, key) == 9
+    assert table.get(key) == 9                                     # the agreed choice wins outside sections too
+    del table[key]
+    table.local.pop(key, None)
 
 
 def test_new_tile_choices_are_decided_by_rank0_and_broadcast():

@@ -4,6 +4,7 @@ The ranks are separate PROCESSES that map each other's receive buffers through H
 they share device 0 (the kernels still exchange tagged granules through each other's buffers and must
 run concurrently), on a multi-GPU node each takes its own device."""
 import os
+import sys
 import socket
 import tempfile
 
@@ -12,6 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -208,3 +210,25 @@ def _fold_sync_worker(rank, world, port):
 
 def test_folded_paths_under_syncbn_equal_global_batch():
     mp.spawn(_fold_sync_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_entrypoint_two_ranks_master_alone_in_a_forward(tmp_path):
+    """`train_pascal.py --gpus 2` (two ranks sharing the device, gloo) through training, validation with per-rank tail
+    batches, the MASTER-ONLY validation figure and the checkpoint barrier.  The figure's forward meets problems no
+    table holds on rank 0 alone: a tile choice that cost a collective there (round 3's rank-0-decides broadcast, before
+    it was confined to `collective_tuning` sections) left rank 0 in a broadcast and rank 1 in the barrier."""
+    import json
+    import subprocess
+    env = dict(os.environ, DPAMD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "train_pascal.py"), "--synthetic", "--model",
+                        "deeplabv3plus_resnet18", "--crop", "129", "--trainBatch", "8", "--testBatch", "8",
+                        "--synthetic-len", "72", "--nEpochs", "2", "--workers", "0", "--log-every", "0",
+                        "--hang-timeout", "90", "--gpus", "2", "--save-dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    recs = [json.loads(l) for l in (tmp_path / "run_0" / "log.jsonl").read_text().splitlines()]
+    vals = [x for x in recs if x.get("kind") == "val"]
+    assert len(vals) == 2 and all(v["path"] == "device" for v in vals)
+    assert (tmp_path / "run_0" / "models").exists()
