@@ -1,4 +1,6 @@
-"""One training step of a model on the GPU kernels (variants) against fp32 on the CPU: gradient cosines."""
+"""One training step of a model on the GPU kernels (variants) against fp32 on the CPU: gradient cosines.
+
+    python tools/diag_model_step.py [model = deeplabv3plus_resnet18] [crop = 97]"""
 import copy, sys, torch, torch.nn.functional as F
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 from test_gpu_hardening import cosine
@@ -6,7 +8,8 @@ from distributedpytorch_amd.models import build_model
 from distributedpytorch_amd.ops import SoftmaxCrossEntropy, sepconv, _hip_conv
 from distributedpytorch_amd.parallel import TrainEngine
 
-name, size = sys.argv[1], int(sys.argv[2])
+name = sys.argv[1] if len(sys.argv) > 1 else "deeplabv3plus_resnet18"
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 97
 kwargs = dict(output_stride=8) if "xception" in name else {}
 torch.manual_seed(0)
 m_cpu = build_model(name, 21, **kwargs).train()
