@@ -24,5 +24,9 @@ if mode == "aux-normal":            # weight-gradient stream at normal priority 
 if mode == "aux-low":
     from distributedpytorch_amd.ops import streams
     streams._PRIORITY = "low"
+if mode.startswith("reps"):           # cap of the statistics replicas (default 8): repsN
+    from distributedpytorch_amd.ops import _hip_conv
+    cap = int(mode[4:])
+    _hip_conv.stat_replicas = lambda m_rows: max(1, min(cap, ((m_rows + 127) // 128) // 64))
 sys.argv = ["bench.py"] + sys.argv[2:]
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
