@@ -588,7 +588,10 @@ def main(argv=None):
         except FloatingPointError as e:
             # every rank raised together (StepGuard all-reduces the flag).  "restore": go back to
             # the last checkpoint this run wrote (weights, momentum, RNG) and redo the epoch — at most 3 times.
-            if args.on_nonfinite != "restore" or last_ckpt is None or restores >= 3:
+            if args.on_nonfinite == "restore" and (last_ckpt is None or restores >= 3):
+                why = "this run has written no checkpoint yet" if last_ckpt is None else "3 restores already"
+                raise FloatingPointError(f"{e} (--on-nonfinite restore: {why})") from e
+            if args.on_nonfinite != "restore":
                 raise
             restores += 1
             extra = load_checkpoint(last_ckpt, engine.ddp, engine.optimizer)
