@@ -511,3 +511,18 @@ def test_device_forms_of_the_unused_transforms_match_the_cpu_transforms():
             grown = ops.expand_bbox(boxes, torch.from_numpy(relax))[b].tolist()
             assert grown == [x0 - t.crop_relax, y0 - t.crop_relax, x1 + t.crop_relax, y1 + t.crop_relax]
     assert ops.expand_bbox(boxes, torch.from_numpy(relax))[3, 2] < ops.expand_bbox(boxes, torch.from_numpy(relax))[3, 0]
+
+
+def test_hostcopy_returns_independent_contiguous_tensors():
+    """utils.hostcopy.to_host (the checkpoint's device -> host path; the device branch runs in
+    tests/test_gpu_runtime.py): values and logical shapes kept, channels-last inputs come back contiguous, every
+    result owns its storage."""
+    from distributedpytorch_amd.utils.hostcopy import to_host
+    a = torch.randn(4, 3, 2, 2).contiguous(memory_format=torch.channels_last)
+    b = torch.arange(5)
+    c = torch.randn(7)[::2]
+    out = to_host([a, b, c])
+    for src, dst in zip((a, b, c), out):
+        assert dst.is_contiguous() and dst.shape == src.shape and dst.dtype == src.dtype and torch.equal(dst, src)
+        assert dst.untyped_storage().data_ptr() != src.untyped_storage().data_ptr()
+    assert len({t.untyped_storage().data_ptr() for t in out}) == 3
