@@ -51,20 +51,6 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, fl
     }
 }
 
-__global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_raw* __restrict__ x, long n, const float* __restrict__ s) {
-    const float k = s[0];
-    const long n8 = n >> 3;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        float f[8];
-        unpack8(reinterpret_cast<uint4*>(x)[i], f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] *= k;
-        reinterpret_cast<uint4*>(x)[i] = pack8(f);
-    }
-    for (long i = (n8 << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        x[i] = f2bf(bf2f(x[i]) * k);
-}
-
 // ----------------------------------------- max-pool -----------------------------------------
 struct Pool { int N, C, Hi, Wi, Ho, Wo; };
 
@@ -336,13 +322,6 @@ DP_EXPORT int dp_sgd_flat(float* p, float* g, float* m, void* p16, long n, float
     if (p16 && ((uintptr_t)p16 & 7)) return -3;
     hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid_1d(n / 4 + 1, 256, 2048)), dim3(256), 0, st, p, g, m,
                        (bf16_raw*)p16, n, lr, mu, wd, gscale, zero_grad, first);
-    return DP_LAUNCH_STATUS();
-}
-
-DP_EXPORT int dp_scale_bf16(void* x, long n, const float* s, hipStream_t st) {
-    if (n <= 0) return 0;
-    if ((uintptr_t)x & 15) return -3;
-    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_1d(n / 8 + 1, 256, 2048)), dim3(256), 0, st, (bf16_raw*)x, n, s);
     return DP_LAUNCH_STATUS();
 }
 

@@ -380,11 +380,6 @@ def _autotune(args, stats, reps, cout, device, runner=None, candidates=None) -> 
     return best[0]
 
 
-def tuned_table() -> dict:
-    """The configurations picked so far (for logs / bench reports)."""
-    return dict(_TUNED)
-
-
 def dgrad_bn_fused(dy: torch.Tensor, wt: torch.Tensor, out_hw, sdiv: int, pad, dil, residual, holder, a=None):
     """Data gradient with the previous layer's BN+ReLU backward prologue fused into the store loop
     (csrc/conv_igemm2.hip, Conv2Args::bnx): returns ``(dm, sums)`` — the ReLU-masked gradient and the

@@ -24,7 +24,6 @@ def _lib():
         lib.dp_bilinear_fwd.argtypes = [V, V, I, I, I, I, I, I, V]
         lib.dp_bilinear_bwd.argtypes = [V, V, I, I, I, I, I, I, V]
         lib.dp_sgd_flat.argtypes = [V, V, V, V, L, F, F, F, F, I, I, V]
-        lib.dp_scale_bf16.argtypes = [V, L, V, V]
         lib.dp_maxpool3x3s2_fwd.argtypes = [V, V, V, I, I, I, I, I, I, V]
         lib.dp_maxpool3x3s2_bwd.argtypes = [V, V, V, I, I, I, I, I, I, V]
         lib.dp_gap_fwd.argtypes = [V, V, I, I, I, V]
@@ -230,13 +229,6 @@ def sgd_flat(p, g, m, p_lowp, lr, momentum, weight_decay, grad_scale, zero_grad,
     B.check(_lib().dp_sgd_flat(B.ptr(p), B.ptr(g), B.ptr(m), B.ptr(p_lowp), p.numel(), float(lr), float(momentum),
                                float(weight_decay), float(grad_scale), int(zero_grad), int(first_step),
                                B.stream_ptr()), "sgd_flat")
-
-
-def scale_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
-    """x *= s (device scalar), in place, bf16."""
-    s = s.detach().reshape(1).float().contiguous()
-    B.check(_lib().dp_scale_bf16(B.ptr(x), x.numel(), B.ptr(s), B.stream_ptr()), "scale_bf16")
-    return x
 
 
 # ------------------------------------------------------------------ augmentation

@@ -42,11 +42,6 @@ def row_stride(t: torch.Tensor) -> Optional[int]:
     return ld if ok else None
 
 
-def slot_view(slot: Slot) -> torch.Tensor:
-    buf, off, c = slot
-    return buf[:, off:off + c]
-
-
 class _Assemble(torch.autograd.Function):
     @staticmethod
     def forward(ctx, buf, offsets, *parts):

@@ -76,11 +76,6 @@ def enabled() -> bool:
     return _ENABLED and not _backend.deterministic()
 
 
-def set_enabled(flag: bool) -> None:
-    global _ENABLED
-    _ENABLED = bool(flag)
-
-
 def set_priority(level: str) -> None:
     """'normal' (default) | 'low'.  Streams that exist already are joined and dropped; the next fork creates new
     ones.  parallel.p2p calls this with 'normal' when ranks SHARE a device (rehearsals): a peer's spinning one-shot

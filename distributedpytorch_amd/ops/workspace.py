@@ -5,7 +5,7 @@ weight gradients) accumulate with atomics into small zeroed buffers.  Allocating
 ``torch.zeros`` costs one fill launch per layer (~350 per training step).  Instead one pooled
 device buffer is zeroed ONCE per step (a single memset on the stream) and sliced: every slice is
 handed out at most once between two ``begin_step()`` calls, so it is guaranteed to still be zero.
-If the pool runs dry (no ``begin_step`` caller, e.g. unit tests) it falls back to ``torch.zeros``.
+If the pool runs dry or was never armed (no ``begin_step`` caller, e.g. unit tests) it falls back to ``torch.zeros``.
 """
 from __future__ import annotations
 
@@ -55,14 +55,6 @@ def begin_step(device: torch.device) -> None:
     if pool is None:
         pool = _pools[device] = _Pool(device)
     pool.begin()
-
-
-def end_step(device: torch.device) -> None:
-    """Disarm: later callers (outside a managed step) get fresh ``torch.zeros``."""
-    pool = _pools.get(device)
-    if pool is not None:
-        pool.begin()
-        pool.armed = False
 
 
 def zeros(n: int, device: torch.device) -> torch.Tensor:

@@ -145,9 +145,6 @@ class ParamArena:
         bk = self.buckets[b]
         return self.flat_g[bk.start:bk.end]
 
-    def lowp_of(self, p: nn.Parameter) -> Optional[torch.Tensor]:
-        return self.lowp_views.get(id(p))
-
     def refresh_lowp(self) -> None:
         if self.flat_lowp is not None:
             with torch.no_grad():
@@ -216,18 +213,6 @@ class ParamArena:
                                            self._wt_tiles)
         for s in self._wt_dense:
             s.param._dpamd_lowpT_ok = True
-
-    def rebind(self) -> None:
-        """Re-attach ``.data``/``.grad`` views (after ``load_state_dict(assign=True)`` or ``.to()``)."""
-        with torch.no_grad():
-            for s in self.slots:
-                view = _view_like(self.flat_p, s.offset, s.param)
-                if s.param.data.data_ptr() != view.data_ptr():
-                    view.copy_(s.param.data)
-                    s.param.data = view
-                s.param.grad = _view_like(self.flat_g, s.offset, s.param)
-                s.param._dpamd_grad_sink = s.param.grad
-        self.refresh_lowp()
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()
