@@ -107,9 +107,14 @@ def main():
 
     # hang watchdog: DPAMD_HANG_DUMP_S=N dumps every thread's Python stack to stderr
     # and exits if the run is still going after N seconds — a stuck collective names its call site
+    import faulthandler
     if os.environ.get("DPAMD_HANG_DUMP_S"):
-        import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DPAMD_HANG_DUMP_S"]), exit=True)
+    else:
+        # no knob set: a run that is still going after 15 minutes (a healthy one takes one or two) writes every
+        # thread's stack to stderr, every 15 minutes, and keeps running — whoever reads the log of a multi-GPU run that
+        # stopped finds out where each rank was
+        faulthandler.dump_traceback_later(900, repeat=True, exit=False)
     if os.environ.get("DPAMD_HEARTBEAT_S"):
         # long silent phases (MIOpen's kernel search on the stock path, first-step autotuning): one line a minute
         import threading
