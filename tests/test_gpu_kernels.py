@@ -184,6 +184,13 @@ WGRAD_CASES = [
     (2, 128, 64, 35, 33, 3, 2, 1, 1),       # strided
     (3, 256, 64, 9, 9, 3, 1, 12, 12),       # halo larger than the map
     (2, 64, 64, 21, 23, 1, 2, 0, 1),        # 1x1 stride 2 (general path with one tap)
+    # K-steps of zeros skipped (two wave groups, Cin % 128 == 0: a block's weight columns lie in one tap)
+    (3, 128, 256, 33, 33, 3, 1, 18, 18),    # ASPP rate 18 on 33x33: 18 of 33 rows are padding for the outer tap rows
+    (2, 256, 256, 65, 65, 3, 1, 36, 36),    # Xception-65 OS8 ASPP rate 36 on 65x65
+    (3, 128, 256, 33, 31, 3, 1, 12, 12),    # rate 12, odd width
+    (2, 128, 256, 17, 17, 3, 2, 6, 6),      # strided and dilated
+    (5, 128, 256, 5, 7, 3, 1, 2, 2),        # tiny map: every step runs over several images (never skipped)
+    (2, 128, 384, 33, 33, 3, 1, 40, 40),    # halo larger than the map: only the centre tap sees pixels
 ]
 
 
