@@ -281,7 +281,13 @@ class GpuBatchLoader:
         loader = DataLoader(self.raw, batch_size=self.batch, sampler=self.sampler, num_workers=self.workers,
                             drop_last=self.drop_last, pin_memory=on_gpu, persistent_workers=False,
                             collate_fn=lambda ss: pad_collate(ss, None, self.label_fill))
-        side = torch.cuda.Stream(device=self.device) if on_gpu else None
+        # ONE copy stream per loader, not one per epoch: the caching allocator keeps a pool per stream, PyTorch hands
+        # out its 32 pool streams round-robin, so a fresh stream every epoch allocated its upload buffers anew each
+        # time and reserved memory grew by half a GiB per epoch (B128: 45.0 -> 50.5 GiB in 10 epochs,
+        # profiles/r3_stream_mode_reserved_growth.md)
+        if on_gpu and getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream if on_gpu else None
 
         def upload(b):
             if not on_gpu:

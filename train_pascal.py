@@ -220,6 +220,20 @@ class StepGuard:
             faulthandler.cancel_dump_traceback_later()
 
 
+def _memory_report(engine) -> dict:
+    """Host resident set of this process and the device allocator's state, per epoch: a leak shows as a slope."""
+    out = {}
+    try:
+        import psutil
+        out["host_rss_gib"] = psutil.Process().memory_info().rss / 2 ** 30
+    except Exception:                                        # psutil is optional
+        pass
+    if engine.on_gpu:
+        out["hbm_allocated_gib"] = torch.cuda.memory_allocated(engine.device) / 2 ** 30
+        out["hbm_reserved_gib"] = torch.cuda.memory_reserved(engine.device) / 2 ** 30
+    return out
+
+
 def train_epoch(engine, loader, scheduler, epoch, args, log, guard=None, checker=None):
     """One epoch.  ``loader`` yields ``(inputs, target)`` — already augmented device tensors on the GPU data path,
     host tensors from the DataLoader workers on the CPU path."""
@@ -611,7 +625,7 @@ def main(argv=None):
             sampler.seed = args.seed + 104729 * restores
             continue
         log.log("epoch", epoch=epoch, numImages=len(trainloader) * args.trainBatch * info.world_size,
-                loss=tr_loss, img_per_s=ips, data_wait_ms=wait_ms)
+                loss=tr_loss, img_per_s=ips, data_wait_ms=wait_ms, **_memory_report(engine))
         if (epoch % args.snapshot) == args.snapshot - 1 and epoch != 0:
             last_ckpt = os.path.join(save_dir, "models", model_name + "_epoch-" + str(epoch) + ".pth")
             save_checkpoint(last_ckpt, engine.ddp, engine.optimizer, {"epoch": epoch, "best_val": best_val},
