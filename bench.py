@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU/gloo (tiny shapes)")
     ap.add_argument("--phases", action="store_true", help="print per-phase HIP-event timings (rank 0)")
+    ap.add_argument("--graph-step", action="store_true",
+                    help="replay the whole training step from one hipGraph (one rank; pays below ~B32, where the "
+                         "host's launches bound the step)")
     ap.add_argument("--record-baseline", action="store_true",
                     help="with --impl stock: store this run in bench_baseline.json")
     ap.add_argument("--source-log", default=None, help="log file name recorded with --record-baseline")
@@ -155,7 +158,7 @@ def main():
     else:
         criterion = SoftmaxCrossEntropy(255)
     engine = TrainEngine(model, criterion, lr=5e-8 if instance else 0.007, momentum=0.9, weight_decay=5e-4,
-                         device=info.device, bucket_mb=args.bucket_mb)
+                         device=info.device, bucket_mb=args.bucket_mb, graph_step=args.graph_step)
     if args.batch <= 0:
         # sized for the 288 GB of HBM3E: 1,037-1,041 img/s at 256 against 1,001 at 128; 320 / 384 / 512 give 1,047 /
         # 1,041-1,059 / 1,034 (profiles/r3_bench_*): flat within the box-to-box spread.  The stock path keeps 128.
@@ -277,7 +280,8 @@ def main():
                      "devices": devices, "buckets": len(engine.ddp.arena.buckets), "bucket_mb": args.bucket_mb,
                      "ddp_mode": engine.ddp.mode, "comm_wait_ms": round(comm_wait, 3),
                      "exposed_comm_ms": round(comm_wait, 3)},
-            "runtime": {"ops_backend": ops.get_backend()},
+            "runtime": {"ops_backend": ops.get_backend(), "graph_step": bool(engine.graph_step),
+                        "graphs_captured": len(engine._graphs)},
         }
         if on_gpu:
             rec["runtime"]["hbm_peak_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)

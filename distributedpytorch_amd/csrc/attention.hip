@@ -842,6 +842,7 @@ DP_EXPORT int dp_head_dropout(const void* a, const void* b, const void* c, void*
     p.n8 = n / 8;
     p.drop.thr = thr; p.drop.scale = 65536.f / (float)(65536u - thr);
     p.drop.seed_lo = (unsigned)seed; p.drop.seed_hi = (unsigned)(seed >> 32);
+    p.drop.word = g_dp_drop_word;                     // captured steps: new masks per replay (common.h)
     long blocks = (p.n8 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (bwd) hipLaunchKernelGGL(head_drop_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);

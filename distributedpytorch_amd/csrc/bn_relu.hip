@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void bn3fold_comb_kernel(const float* __restri
 }
 
 // set by dp_bn_set_dropout for the NEXT apply_stats / bwd_reduce / bwd_apply launch of this thread
-thread_local Drop t_drop = {0u, 1.f, 0u, 0u};
+thread_local Drop t_drop = {0u, 1.f, 0u, 0u, nullptr};
 
 // row strides (in elements) of the NEXT launch's y (apply) / dy (backward): set by dp_bn_set_ld, 0 = C
 thread_local long t_ld = 0;
@@ -708,8 +708,9 @@ inline long take_ld8(int C) {
 }
 
 inline Drop take_drop() {
-    const Drop d = t_drop;
-    t_drop = Drop{0u, 1.f, 0u, 0u};
+    Drop d = t_drop;
+    t_drop = Drop{0u, 1.f, 0u, 0u, nullptr};
+    d.word = d.thr ? g_dp_drop_word : nullptr;
     return d;
 }
 

@@ -48,7 +48,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Counter-based dropout: the keep decision of an element is a hash of (element index, seed), 16 bits per element,
 // so backward kernels RECOMPUTE it — no mask tensor.  thr = round(p·65536) (0 = off), scale = 1 / (1 − thr/65536).
-struct Drop { unsigned thr; float scale; unsigned seed_lo, seed_hi; };
+struct Drop { unsigned thr; float scale; unsigned seed_lo, seed_hi;
+              const unsigned* word; };   // optional device word mixed into the key (see g_dp_drop_word below), or null
 
 __device__ __forceinline__ unsigned drop_hash(unsigned lo, unsigned hi, const Drop& d) {
     unsigned x = lo ^ d.seed_lo;
@@ -59,8 +60,10 @@ __device__ __forceinline__ unsigned drop_hash(unsigned lo, unsigned hi, const Dr
 }
 
 // keep bits of the 8 elements of 16-byte chunk q (bit j = element j)
-__device__ __forceinline__ unsigned drop_keep8(long q, const Drop& d) {
+__device__ __forceinline__ unsigned drop_keep8(long q, const Drop& d0) {
     const unsigned long long e = (unsigned long long)q * 4ull;
+    Drop d = d0;
+    if (d0.word) d.seed_hi ^= d0.word[0] * 0x9E3779B9u;       // a uniform load; forward and backward read the same word
     unsigned keep = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -78,6 +81,12 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // writer (row splits = 1, one replica per block, split-K = 1); the Python wrappers sum the replicas in a fixed
 // order.  Two identical launches are then bit-identical.  Host-side flag only: no kernel reads it.
 extern "C" int g_dp_deterministic;
+
+// Captured training steps (parallel/engine.py, hipGraph replay): a kernel argument is frozen at capture, so whatever
+// must change from step to step lives in device memory.  g_dp_drop_word (set by dp_set_drop_word; null = off): a device
+// counter the captured step increments first thing, mixed into every fused dropout's key — a replay draws new masks,
+// and its backward, reading the same word, recomputes the same ones.  Launchers copy the pointer into Drop::word.
+extern "C" const unsigned* g_dp_drop_word;
 
 // Launch-status helper: launchers return hipGetLastError() as int (0 = ok).
 #define DP_LAUNCH_STATUS() ((int)hipGetLastError())

@@ -17,7 +17,10 @@ inline int grid_1d(long total, int threads, int cap = 256 * 16) {
 __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, float* __restrict__ g,
                                                        float* __restrict__ m, bf16_raw* __restrict__ p16, long n,
                                                        float lr, float mu, float wd, float gscale, int zero_grad,
-                                                       int first) {
+                                                       int first, const float* __restrict__ lr_scale /* = lr_dev */) {
+    // lr_dev (or null): the learning rate in device memory — a captured step (hipGraph) freezes the `lr` argument, the
+    // schedule then writes this scalar between replays (dp_sgd_set_lr_ptr; one per parameter group)
+    if (lr_scale) lr = lr_scale[0];
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -309,6 +312,10 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const bf16_raw* __restri
 }  // namespace
 
 int g_dp_deterministic = 0;
+const unsigned* g_dp_drop_word = nullptr;
+namespace { const float* g_lr_scale = nullptr; }
+DP_EXPORT int dp_set_drop_word(const void* dev_word) { g_dp_drop_word = (const unsigned*)dev_word; return 0; }
+DP_EXPORT int dp_sgd_set_lr_ptr(const void* dev_scalar) { g_lr_scale = (const float*)dev_scalar; return 0; }
 DP_EXPORT int dp_set_deterministic(int on) {
     const int old = g_dp_deterministic;
     g_dp_deterministic = on ? 1 : 0;
@@ -321,7 +328,7 @@ DP_EXPORT int dp_sgd_flat(float* p, float* g, float* m, void* p16, long n, float
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15) return -3;
     if (p16 && ((uintptr_t)p16 & 7)) return -3;
     hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid_1d(n / 4 + 1, 256, 2048)), dim3(256), 0, st, p, g, m,
-                       (bf16_raw*)p16, n, lr, mu, wd, gscale, zero_grad, first);
+                       (bf16_raw*)p16, n, lr, mu, wd, gscale, zero_grad, first, g_lr_scale);
     return DP_LAUNCH_STATUS();
 }
 

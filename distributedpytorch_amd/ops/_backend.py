@@ -164,6 +164,10 @@ def lib() -> ctypes.CDLL:
                 else:
                     _ensure_current()
                     _lib = ctypes.CDLL(LIB_PATH)
+                for fn in ("dp_set_drop_word", "dp_sgd_set_lr_ptr"):        # captured steps (parallel/engine.py)
+                    if hasattr(_lib, fn):
+                        getattr(_lib, fn).argtypes = [ctypes.c_void_p]
+                        getattr(_lib, fn).restype = ctypes.c_int
                 _sync_det()
     return _lib
 

@@ -38,11 +38,23 @@ def named_lr_groups(model: nn.Module, head_lr_mult: float = 1.0):
     return [base, head], [1.0, head_lr_mult]
 
 
+class _NullTimerT:
+    from contextlib import contextmanager as _cm
+
+    @_cm
+    def phase(self, name: str):
+        yield
+
+
+_NullTimer = _NullTimerT()
+
+
 class TrainEngine:
     def __init__(self, model: nn.Module, criterion: Callable, lr: float = 0.007, momentum: float = 0.9,
                  weight_decay: float = 5e-4, head_lr_mult: float = 1.0,
                  device: Optional[torch.device] = None, compute_dtype: Optional[torch.dtype] = None,
-                 bucket_mb: int = 64, accum_steps: int = 1, process_group=None, markers: bool = False):
+                 bucket_mb: int = 64, accum_steps: int = 1, process_group=None, markers: bool = False,
+                 graph_step: bool = False):
         self.device = device or torch.device("cpu")
         self.on_gpu = self.device.type == "cuda"
         self.compute_dtype = compute_dtype or (torch.bfloat16 if self.on_gpu else torch.float32)
@@ -65,6 +77,16 @@ class TrainEngine:
         self.timer = PhaseTimer(self.on_gpu, markers)
         self.global_step = 0
         self._step_events: list = []      # bounds how far the host may run ahead of the GPU
+        # graph_step: the whole step (forward, loss, backward, fused SGD, transposing refresh) replayed from ONE hipGraph
+        # per input shape (see _train_step_graphed).  Below ~B32 the R101 step is bound by the host's ~900 launches
+        # (B8 and B16 both take 29 ms eagerly); a replay costs what the device needs.
+        self.graph_step = bool(graph_step) and self.on_gpu
+        self._graphs: dict = {}
+        self._graph_warm: dict = {}
+        if self.graph_step:
+            if self.ddp._comm or self.accum_steps != 1:
+                raise NotImplementedError("graph_step: one rank, no gradient accumulation (the bucket collectives and the "
+                                          "no_sync micro-steps are host-driven)")
         # Stream priorities (history; ops/streams.py has the current state): a LOW-priority weight-gradient stream
         # was worth 951 -> 957-958 img/s at B128 in round 1 and nothing measurable on R101 at the end of round 3, and
         # stalled a step in a process with several other streams — every stream runs at normal priority now.  A
@@ -86,24 +108,39 @@ class TrainEngine:
         x = self.prepare_input(images)
         # TODO `train_pascal.py:5`: "label non_blocking = True"
         y = target.to(self.device, non_blocking=True)
-        last_micro = (self._micro + 1) % self.accum_steps == 0
+        if self.graph_step:
+            return self._train_step_graphed(x, y)
+        return self._train_step_eager(x, y)
+
+    def _bound_run_ahead(self) -> None:
+        # The loss is never read on the host, so nothing stops Python from queueing steps faster than
+        # the GPU retires them, and the caching allocator then grows without bound (B128: 280 GiB, OOM).
+        # Wait for the step before the previous one: two steps in flight keep the queues full.
+        if self.on_gpu and len(self._step_events) >= 2:
+            self._step_events.pop(0).synchronize()
+
+    def _mark_step_end(self) -> None:
         if self.on_gpu:
-            # The loss is never read on the host, so nothing stops Python from queueing steps faster than
-            # the GPU retires them, and the caching allocator then grows without bound (B128: 280 GiB, OOM).
-            # Wait for the step before the previous one: two steps in flight keep the queues full.
-            if len(self._step_events) >= 2:
-                self._step_events.pop(0).synchronize()
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_events.append(ev)
+
+    def _train_step_eager(self, x: torch.Tensor, y: torch.Tensor, capturing: bool = False) -> torch.Tensor:
+        last_micro = (self._micro + 1) % self.accum_steps == 0
+        if not capturing:
+            self._bound_run_ahead()
+        timer = _NullTimer if capturing else self.timer           # timed events do not belong into a capture
         workspace.begin_step(self.device)   # one memset re-arms every reduction accumulator of the step
         # forward + backward of a training step: the one place where every rank runs the same launches in the same
         # order, hence the only place where a new problem's tile choice may be a collective (rank 0 measures)
         from ..ops import _hip_conv
         with _hip_conv.collective_tuning():
-            with self.timer.phase("fwd"):
+            with timer.phase("fwd"):
                 out = self.ddp(x)
                 loss = self.criterion(out, y)
                 if self.accum_steps > 1:
                     loss = loss / self.accum_steps
-            with self.timer.phase("bwd"):
+            with timer.phase("bwd"):
                 if last_micro:
                     loss.backward()
                 else:
@@ -111,30 +148,83 @@ class TrainEngine:
                         loss.backward()
         self._micro += 1
         if last_micro:
-            with self.timer.phase("comm_wait"):
+            with timer.phase("comm_wait"):
                 scale = self.ddp.finish_gradient_sync()
             from . import debug
-            if debug.ENABLED:
+            if debug.ENABLED and not capturing:
                 debug.check_streams_joined(self.device)
-            with self.timer.phase("optim"):
+            with timer.phase("optim"):
                 self.optimizer.step(grad_scale=scale, zero_grad=True)
             self.global_step += 1
-            if self.on_gpu:
-                ev = torch.cuda.Event()
-                ev.record()
-                self._step_events.append(ev)
-            if debug.ENABLED and self.global_step % 10 == 1:
+            if not capturing:
+                self._mark_step_end()
+            if debug.ENABLED and not capturing and self.global_step % 10 == 1:
                 # running statistics are rank-local unless every BatchNorm is synchronised
                 bns = [m for m in self.model.modules() if hasattr(m, "running_mean") and hasattr(m, "sync")]
                 all_sync = bool(bns) and all(m.sync for m in bns)
                 debug.check_replicas_equal(self.ddp.arena.flat_p, self.model.buffers() if all_sync else ())
             from . import p2p
-            if p2p._default is not None:
+            if p2p._default is not None and not capturing:
                 if self.global_step == 1:
                     p2p.check_first_step()    # a timed-out (partial) reduction must never feed a second step
                 elif self.global_step % p2p.CHECK_EVERY == 0:
                     p2p._default.check()      # a peer that never arrived (bounded spin) surfaces here
         return loss.detach()
+
+    # ------------------------------------------------------------------ the step as one hipGraph
+    _GRAPH_WARMUP = 3
+
+    def _train_step_graphed(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """One hipGraph per input shape.  The first steps of a shape run eagerly (tile choices, lazy initialisation, the
+        first-step form of the momentum update), the next one is captured — a capture records, it does not execute — and
+        replayed at once, so every batch trains exactly once.  What changes from step to step cannot be a kernel
+        argument (frozen at capture): the inputs are copied into static buffers, the learning rate reaches the SGD
+        kernels through one device scalar per parameter group that the schedule writes, and the fused dropouts mix a
+        device counter, incremented by the captured step itself, into their keys (csrc/common.h: g_dp_drop_word)."""
+        key = (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype)
+        st = self._graphs.get(key)
+        if st is None:
+            n = self._graph_warm.get(key, 0)
+            if n < self._GRAPH_WARMUP:
+                self._graph_warm[key] = n + 1
+                return self._train_step_eager(x, y)
+            st = self._capture_step(x, y)
+            self._graphs[key] = st
+        self._bound_run_ahead()
+        if st["x"].data_ptr() != x.data_ptr():
+            st["x"].copy_(x)
+        if st["y"].data_ptr() != y.data_ptr():
+            st["y"].copy_(y)
+        for g, pg in enumerate(self.optimizer.param_groups):          # (fill kernels: no host-to-device copy)
+            st["lr_dev"][g:g + 1].fill_(float(pg["lr"]))
+        st["graph"].replay()
+        self.global_step += 1
+        self.optimizer._steps += 1
+        self._mark_step_end()
+        return st["loss"]
+
+    def _capture_step(self, x: torch.Tensor, y: torch.Tensor) -> dict:
+        from ..ops import _backend
+        lib = _backend.lib()
+        st = {"x": x.clone(memory_format=torch.preserve_format), "y": y.clone(),
+              "lr_dev": torch.zeros(len(self.optimizer.param_groups), dtype=torch.float32, device=self.device),
+              "drop_word": torch.zeros(1, dtype=torch.int32, device=self.device)}
+        steps_before, global_before, micro_before = self.optimizer._steps, self.global_step, self._micro
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        lib.dp_set_drop_word(st["drop_word"].data_ptr())
+        self.optimizer.lr_dev = st["lr_dev"]
+        try:
+            with torch.cuda.graph(graph):
+                st["drop_word"].add_(1)
+                st["loss"] = self._train_step_eager(st["x"], st["y"], capturing=True)
+        finally:
+            lib.dp_set_drop_word(None)            # the pointers are kernel arguments of the capture now; eager
+            self.optimizer.lr_dev = None          # launches (validation, another engine) see none
+        # nothing ran: undo the bookkeeping of the recorded step (the replay that follows does its own)
+        self.optimizer._steps, self.global_step, self._micro = steps_before, global_before, micro_before
+        st["graph"] = graph
+        return st
 
     @torch.no_grad()
     def evaluate(self, loader: Iterable, num_classes: int, ignore_index: int = 255,

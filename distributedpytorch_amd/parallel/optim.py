@@ -34,6 +34,9 @@ class FlatSGD:
             for g in range(ngroups)
         ]
         self._steps = 0
+        # set by a capturing TrainEngine (graph_step): fp32 [groups] on the device — the SGD launches of a captured
+        # step read their learning rate from here instead of from the (frozen) kernel argument
+        self.lr_dev: Optional[torch.Tensor] = None
 
     def __str__(self) -> str:
         g = self.param_groups[0]
@@ -43,12 +46,22 @@ class FlatSGD:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         a = self.arena
-        for (st, en, g) in a.segments:
-            pg = self.param_groups[g]
-            lowp = a.flat_lowp[st:en] if a.flat_lowp is not None else None
-            sgd_flat_step_(a.flat_p[st:en], a.flat_g[st:en], a.flat_m[st:en], lowp,
-                           pg["lr"], pg["momentum"], pg["weight_decay"], grad_scale,
-                           zero_grad, first_step=(self._steps == 0))
+        lib = None
+        if self.lr_dev is not None:
+            from ..ops import _backend
+            lib = _backend.lib()
+        try:
+            for (st, en, g) in a.segments:
+                pg = self.param_groups[g]
+                lowp = a.flat_lowp[st:en] if a.flat_lowp is not None else None
+                if lib is not None:
+                    lib.dp_sgd_set_lr_ptr(self.lr_dev[g:g + 1].data_ptr())
+                sgd_flat_step_(a.flat_p[st:en], a.flat_g[st:en], a.flat_m[st:en], lowp,
+                               pg["lr"], pg["momentum"], pg["weight_decay"], grad_scale,
+                               zero_grad, first_step=(self._steps == 0))
+        finally:
+            if lib is not None:
+                lib.dp_sgd_set_lr_ptr(None)
         self._steps += 1
         a.refresh_transposed()      # dgrad weights of every conv, one launch (no-op off the HIP path)
         if a.flat_lowp is not None and not a.flat_p.is_cuda:

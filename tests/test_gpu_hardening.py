@@ -493,3 +493,78 @@ def test_bottleneck_tail_fold_matches_fp32_cpu(stride):
         rp = float((gp[k] - gref[k]).norm() / gref[k].norm().clamp_min(1e-12))
         assert rf < max(1.5 * rp, rp + 0.02), (k, rf, rp)
     assert cosine(dxf, dxp) > 0.995
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(getattr(m, "p_drop", None), tuple):
+            m.p_drop = (0.0, 0.0)
+        elif hasattr(m, "p_drop"):
+            m.p_drop = 0.0
+    return model
+
+
+@pytest.mark.parametrize("name,kwargs", [("deeplabv3plus_resnet50", dict()),
+                                         ("deeplabv3plus_xception65", dict(output_stride=16))])
+def test_graph_step_replays_train_exactly_like_eager_steps(name, kwargs):
+    """TrainEngine(graph_step=True): the whole step replayed from one hipGraph.  Deterministic mode, dropout off: eight
+    steps with a moving learning rate (two parameter groups at 1x / 10x) and a new batch each time give BIT-identical
+    losses and weights to the eager engine — the inputs reach the replay through static buffers, the learning rate through
+    the device scalar, and the capture itself trains nothing."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(0)
+    base = _no_dropout(build_model(name, 21, **kwargs))
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(4, 3, 97, 97, generator=g) for _ in range(8)]
+    ys = [torch.randint(0, 21, (4, 97, 97), generator=g, dtype=torch.uint8) for _ in range(8)]
+    out = {}
+    with B.deterministic_mode(True):
+        for mode in ("eager", "graph"):
+            eng = TrainEngine(copy.deepcopy(base), SoftmaxCrossEntropy(255), lr=0.01, momentum=0.9, weight_decay=1e-4,
+                              head_lr_mult=10.0, device=torch.device("cuda", 0), graph_step=mode == "graph")
+            losses = []
+            for i, (x, y) in enumerate(zip(xs, ys)):
+                for pg, mult in zip(eng.optimizer.param_groups, (1.0, 10.0)):
+                    pg["lr"] = 0.01 * mult * (1.0 - i / 10.0) ** 0.9
+                losses.append(eng.train_step(x.cuda(), y.cuda()).detach().float().cpu().clone())
+            torch.cuda.synchronize()
+            out[mode] = (losses, [p.detach().float().cpu().clone() for p in eng.model.parameters()],
+                         eng.global_step, eng.optimizer._steps, len(eng._graphs))
+    (l1, p1, gs1, os1, ng1), (l2, p2, gs2, os2, ng2) = out["eager"], out["graph"]
+    assert ng1 == 0 and ng2 == 1 and gs1 == gs2 == 8 and os1 == os2 == 8
+    assert all(torch.isfinite(a).all() for a in l1)
+    assert all(torch.equal(a, b) for a, b in zip(l1, l2)), ([float(a) for a in l1], [float(a) for a in l2])
+    bad = [i for i, (a, b) in enumerate(zip(p1, p2)) if not torch.equal(a, b)]
+    assert not bad, f"{len(bad)} of {len(p1)} parameters differ between eager and replayed steps"
+
+
+def test_graph_step_draws_new_dropout_masks_per_replay_and_runs_the_aux_stream():
+    """Default mode (weight gradients on the auxiliary stream inside the capture), dropout on: the same batch replayed
+    at learning rate 0 gives a different loss every time — the fused dropouts mix the device counter the captured step
+    increments into their keys — and the same weights; with dropout off the losses repeat exactly."""
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(0)
+    base = build_model("deeplabv3plus_resnet50", 21)
+    x = torch.randn(4, 3, 97, 97).cuda()
+    y = torch.randint(0, 21, (4, 97, 97), dtype=torch.uint8).cuda()
+    for drop in (True, False):
+        model = copy.deepcopy(base) if drop else _no_dropout(copy.deepcopy(base))
+        with B.deterministic_mode(not drop):          # (dropout off: deterministic, so that equal means bit-equal)
+            eng = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.0, momentum=0.0, weight_decay=0.0,
+                              device=torch.device("cuda", 0), graph_step=True)
+            w0 = [p.detach().clone() for p in eng.model.parameters()]
+            losses = [float(eng.train_step(x, y)) for _ in range(9)]
+        assert len(eng._graphs) == 1
+        replayed = losses[4:]                         # steps 0-2 eager, step 3 = capture + first replay
+        assert all(math.isfinite(v) for v in replayed)
+        if drop:
+            assert len({round(v, 6) for v in replayed}) == len(replayed), replayed
+            assert int(next(iter(eng._graphs.values()))["drop_word"].item()) == 6
+        else:
+            assert max(replayed) == min(replayed), replayed
+        # learning rate 0: only the BatchNorm running statistics move, the parameters do not
+        assert all(torch.equal(a, b.detach()) for a, b in zip(w0, eng.model.parameters()))

@@ -108,6 +108,9 @@ def parse_args(argv=None):
     ap.add_argument("--hang-timeout", type=int, default=int(os.environ.get("DPAMD_HANG_DUMP_S", "0")),
                     help="seconds without a finished log interval before every thread's stack is dumped and the "
                          "rank exits (0 = off)")
+    ap.add_argument("--graph-step", action="store_true",
+                    help="replay the training step from one hipGraph per input shape (one rank, no accumulation): the "
+                         "small-batch regime, where the host's ~900 launches per step are the bound")
     ap.add_argument("--finite-every", type=int, default=50, help="steps between host reads of the device-side "
                     "non-finite-loss flag")
     ap.add_argument("--on-nonfinite", choices=["abort", "restore"], default="abort",
@@ -505,7 +508,7 @@ def main(argv=None):
     criterion = SegmentationMultiLosses(nclass) if instance else ops.SoftmaxCrossEntropy(255)
     engine = TrainEngine(net, criterion, lr=args.lr, momentum=args.momentum, weight_decay=args.wd,
                          head_lr_mult=args.head_lr_mult, device=info.device, bucket_mb=args.bucket_mb,
-                         accum_steps=args.nAveGrad)
+                         accum_steps=args.nAveGrad, graph_step=args.graph_step)
     if args.weights:
         load_weights(args.weights, engine.ddp, strict=False)
     best_val = 0.0
