@@ -215,7 +215,10 @@ class TrainEngine:
         lib.dp_set_drop_word(st["drop_word"].data_ptr())
         self.optimizer.lr_dev = st["lr_dev"]
         try:
-            with torch.cuda.graph(graph):
+            # thread_local: calls that are unsafe during a capture are checked for THIS thread only — a loader's
+            # pin-memory thread (host data path, stream mode) allocating or copying next to the capture invalidated it
+            # in the default (global) mode; the autograd thread's launches go to the capturing stream either way
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 st["drop_word"].add_(1)
                 st["loss"] = self._train_step_eager(st["x"], st["y"], capturing=True)
         finally:
