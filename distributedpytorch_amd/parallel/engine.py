@@ -85,6 +85,9 @@ class TrainEngine:
         self._graph_warm: dict = {}
         if self.graph_step:
             if self.ddp._comm or self.accum_steps != 1:
+                # (RCCL collectives are stream work a capture could record, and a 1-rank forced group was tried: the
+                # process group's watchdog thread queries the events of the captured collectives —
+                # hipErrorCapturedEvent, abort.  Bucket collectives stay host-launched; graph_step is a one-rank mode.)
                 raise NotImplementedError("graph_step: one rank, no gradient accumulation (the bucket collectives and the "
                                           "no_sync micro-steps are host-driven)")
         # Stream priorities (history; ops/streams.py has the current state): a LOW-priority weight-gradient stream
