@@ -84,12 +84,16 @@ class TrainEngine:
         self._graphs: dict = {}
         self._graph_warm: dict = {}
         if self.graph_step:
-            if self.ddp._comm or self.accum_steps != 1:
-                # (RCCL collectives are stream work a capture could record, and a 1-rank forced group was tried: the
-                # process group's watchdog thread queries the events of the captured collectives —
-                # hipErrorCapturedEvent, abort.  Bucket collectives stay host-launched; graph_step is a one-rank mode.)
-                raise NotImplementedError("graph_step: one rank, no gradient accumulation (the bucket collectives and the "
-                                          "no_sync micro-steps are host-driven)")
+            if self.accum_steps != 1:
+                raise NotImplementedError("graph_step: no gradient accumulation (no_sync micro-steps are decided on the host)")
+            if self.ddp._comm and any(getattr(m, "sync", False) for m in model.modules()):
+                raise NotImplementedError("graph_step with several ranks: no synchronised BatchNorm (its collectives "
+                                          "would sit inside the captured forward and backward)")
+            # Several ranks: the capture holds forward + backward only; the bucket collectives and the SGD update are
+            # launched by the host after every replay (a handful of launches).  RCCL collectives INSIDE a capture were
+            # tried on a forced 1-rank group: the process group's watchdog thread queries the events of the captured
+            # collectives (hipErrorCapturedEvent, abort) — and gloo's run on the host anyway.  The price is that the
+            # gradient exchange no longer overlaps backward: ~236 MB for R101, about a millisecond over xGMI.
         # Stream priorities (history; ops/streams.py has the current state): a LOW-priority weight-gradient stream
         # was worth 951 -> 957-958 img/s at B128 in round 1 and nothing measurable on R101 at the end of round 3, and
         # stalled a step in a process with several other streams — every stream runs at normal priority now.  A
@@ -128,7 +132,9 @@ class TrainEngine:
             ev.record()
             self._step_events.append(ev)
 
-    def _train_step_eager(self, x: torch.Tensor, y: torch.Tensor, capturing: bool = False) -> torch.Tensor:
+    def _train_step_eager(self, x: torch.Tensor, y: torch.Tensor, capturing=False) -> torch.Tensor:
+        """``capturing``: False (an eager step), "whole" (recorded into a graph: forward ... SGD) or "fwd_bwd" (several
+        ranks: forward + backward recorded, gradient hooks silent; _finish_replayed_step does the rest on the host)."""
         last_micro = (self._micro + 1) % self.accum_steps == 0
         if not capturing:
             self._bound_run_ahead()
@@ -144,11 +150,15 @@ class TrainEngine:
                 if self.accum_steps > 1:
                     loss = loss / self.accum_steps
             with timer.phase("bwd"):
-                if last_micro:
+                if last_micro and capturing != "fwd_bwd":
                     loss.backward()
                 else:
                     with self.ddp.no_sync():
                         loss.backward()
+        if capturing == "fwd_bwd":
+            from ..ops import streams
+            streams.join(self.device)            # the weight-gradient stream rejoins the capturing stream
+            return loss.detach()
         self._micro += 1
         if last_micro:
             with timer.phase("comm_wait"):
@@ -198,11 +208,17 @@ class TrainEngine:
             st["x"].copy_(x)
         if st["y"].data_ptr() != y.data_ptr():
             st["y"].copy_(y)
-        for g, pg in enumerate(self.optimizer.param_groups):          # (fill kernels: no host-to-device copy)
-            st["lr_dev"][g:g + 1].fill_(float(pg["lr"]))
-        st["graph"].replay()
+        if st["mode"] == "whole":
+            for g, pg in enumerate(self.optimizer.param_groups):      # (fill kernels: no host-to-device copy)
+                st["lr_dev"][g:g + 1].fill_(float(pg["lr"]))
+            st["graph"].replay()
+            self.optimizer._steps += 1
+        else:
+            st["graph"].replay()
+            # several ranks: every bucket is launched now (no hook fired during the replay), then the update
+            scale = self.ddp.finish_gradient_sync()
+            self.optimizer.step(grad_scale=scale, zero_grad=True)
         self.global_step += 1
-        self.optimizer._steps += 1
         self._mark_step_end()
         return st["loss"]
 
@@ -212,18 +228,19 @@ class TrainEngine:
         st = {"x": x.clone(memory_format=torch.preserve_format), "y": y.clone(),
               "lr_dev": torch.zeros(len(self.optimizer.param_groups), dtype=torch.float32, device=self.device),
               "drop_word": torch.zeros(1, dtype=torch.int32, device=self.device)}
+        st["mode"] = "fwd_bwd" if self.ddp._comm else "whole"
         steps_before, global_before, micro_before = self.optimizer._steps, self.global_step, self._micro
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         lib.dp_set_drop_word(st["drop_word"].data_ptr())
-        self.optimizer.lr_dev = st["lr_dev"]
+        self.optimizer.lr_dev = st["lr_dev"] if st["mode"] == "whole" else None
         try:
             # thread_local: calls that are unsafe during a capture are checked for THIS thread only — a loader's
             # pin-memory thread (host data path, stream mode) allocating or copying next to the capture invalidated it
             # in the default (global) mode; the autograd thread's launches go to the capturing stream either way
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 st["drop_word"].add_(1)
-                st["loss"] = self._train_step_eager(st["x"], st["y"], capturing=True)
+                st["loss"] = self._train_step_eager(st["x"], st["y"], capturing=st["mode"])
         finally:
             lib.dp_set_drop_word(None)            # the pointers are kernel arguments of the capture now; eager
             self.optimizer.lr_dev = None          # launches (validation, another engine) see none

@@ -232,3 +232,54 @@ def test_entrypoint_two_ranks_master_alone_in_a_forward(tmp_path):
     vals = [x for x in recs if x.get("kind") == "val"]
     assert len(vals) == 2 and all(v["path"] == "device" for v in vals)
     assert (tmp_path / "run_0" / "models").exists()
+
+
+def _graph_step_ddp_worker(rank, world, port):
+    """Two ranks, graph-step: forward + backward replayed from a hipGraph, bucket collectives and the SGD update
+    launched by the host after each replay.  Deterministic mode, dropout off: bit-identical to the eager two-rank
+    engine on the same batches, replicas identical."""
+    import copy
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", DPAMD_DIST_BACKEND="gloo")
+    from distributedpytorch_amd.models import build_model
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy, _backend
+    from distributedpytorch_amd.parallel import TrainEngine, dist_env, init_distributed
+    info = init_distributed()
+    try:
+        torch.manual_seed(3)
+        base = build_model("deeplabv3plus_resnet18", 21)
+        for m in base.modules():
+            if isinstance(getattr(m, "p_drop", None), tuple):
+                m.p_drop = (0.0, 0.0)
+            elif hasattr(m, "p_drop"):
+                m.p_drop = 0.0
+        g = torch.Generator().manual_seed(50 + rank)
+        xs = [torch.randn(2, 3, 97, 97, generator=g).to(info.device) for _ in range(7)]
+        ys = [torch.randint(0, 21, (2, 97, 97), generator=g).to(info.device) for _ in range(7)]
+        res = {}
+        with _backend.deterministic_mode(True):
+            for mode in ("eager", "graph"):
+                eng = TrainEngine(copy.deepcopy(base), SoftmaxCrossEntropy(255), lr=0.01, momentum=0.9, device=info.device,
+                                  bucket_mb=4, graph_step=mode == "graph")
+                losses = []
+                for i, (x, y) in enumerate(zip(xs, ys)):
+                    eng.optimizer.param_groups[0]["lr"] = 0.01 * (1.0 - i / 10.0)
+                    losses.append(float(eng.train_step(x, y)))
+                torch.cuda.synchronize()
+                res[mode] = (losses, eng.ddp.arena.flat_p.detach().cpu().clone(), len(eng._graphs),
+                             eng.ddp.stats["buckets_launched"], len(eng.ddp.arena.buckets))
+        (l1, p1, n1, b1, nb), (l2, p2, n2, b2, _) = res["eager"], res["graph"]
+        assert n1 == 0 and n2 == 1 and b1 == b2 == 7 * nb, (n1, n2, b1, b2, nb)
+        assert l1 == l2, (rank, l1, l2)
+        assert torch.equal(p1, p2), "graph-step replicas differ from the eager ones"
+        other = p2.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(p2, other), "replicas diverged"
+    finally:
+        dist_env.shutdown()
+
+
+def test_graph_step_with_two_ranks_equals_the_eager_engine():
+    mp.spawn(_graph_step_ddp_worker, args=(2, _free_port()), nprocs=2, join=True)
