@@ -37,7 +37,8 @@ class GraphedForward:
         torch.cuda.current_stream(x.device).wait_stream(side)
         torch.cuda.synchronize(x.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
+        # (thread_local: a loader's pin-memory thread copying next to the capture must not invalidate it)
+        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             static_out = self.model(static_in)
         return graph, static_in, static_out
 
