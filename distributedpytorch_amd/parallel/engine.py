@@ -249,6 +249,16 @@ class TrainEngine:
         st["graph"] = graph
         return st
 
+    def inference_forward(self, graph: bool = False):
+        """The model's forward for evaluation loops (call ``model.eval()`` first): the module itself, or — ``graph`` on a
+        GPU — its replay from a hipGraph per input shape (parallel.graphs; the result is valid until the next call)."""
+        if graph and self.on_gpu:
+            if getattr(self, "_graphed", None) is None:
+                from .graphs import GraphedForward
+                self._graphed = GraphedForward(self.model)
+            return self._graphed
+        return self.model
+
     @torch.no_grad()
     def evaluate(self, loader: Iterable, num_classes: int, ignore_index: int = 255,
                  max_batches: Optional[int] = None, graph: bool = False) -> Dict[str, float]:
@@ -257,12 +267,7 @@ class TrainEngine:
         ``graph=True`` (GPU): the forward is replayed from a hipGraph per input shape — the
         reference's batch-1 evaluation is launch-bound (parallel.graphs)."""
         self.model.eval()
-        fwd = self.model
-        if graph and self.on_gpu:
-            if getattr(self, "_graphed", None) is None:
-                from .graphs import GraphedForward
-                self._graphed = GraphedForward(self.model)
-            fwd = self._graphed
+        fwd = self.inference_forward(graph)
         cm = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=self.device)
         loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         n = 0

@@ -228,9 +228,10 @@ class StepGuard:
 
 
 def _graph_eval(args) -> bool:
-    if args.graph_eval != "auto":
-        return args.graph_eval == "on"
-    return bool(args.graph_step) or args.testBatch <= 4
+    mode = getattr(args, "graph_eval", "auto")               # (callers outside main() pass their own namespace)
+    if mode != "auto":
+        return mode == "on"
+    return bool(getattr(args, "graph_step", False)) or getattr(args, "testBatch", 1) <= 4
 
 
 def _memory_report(engine) -> dict:
@@ -386,12 +387,13 @@ def validate_instance_device(engine, loader, args, epoch=0, fig_path=None, tick=
     dev = engine.device
     acc = torch.zeros(5, dtype=torch.float64, device=dev)            # Σ jaccard (3 thresholds), Σ loss, #objects
     t0, n_img = timeit.default_timer(), 0
+    fwd = engine.inference_forward(_graph_eval(args))                # testBatch <= 4: replayed from a hipGraph
     for ii, (x, y, meta) in enumerate(loader.iter_eval()):
         if args.max_iters and ii >= args.max_iters:
             break
         if tick is not None:
             tick()
-        out = engine.model(engine.prepare_input(x))
+        out = fwd(engine.prepare_input(x))
         outs = out if isinstance(out, (tuple, list)) else (out,)
         bb = meta["crop_bbox"]
         has = (bb[:, 2] >= bb[:, 0]).double()                        # an empty mask has no box: skipped, as on the host
