@@ -47,6 +47,11 @@ struct Conv2Args {
     int ldres;              //   gradient of a residual block joins the data gradient here, no add kernel)
     const float* res_scale; const float* res_shift;   // [Cout] or null: the store loop adds res * scale + shift
                             //   (ops.sepconv: the statistics term of a folded BatchNorm's data gradient)
+    // Inference epilogue (dp_conv_igemm2e): y = act(conv * oscale + bias [+ res]) — an evaluation-mode BatchNorm
+    // (per-channel scale | shift of its running statistics) and the ReLU behind it leave with the convolution's own
+    // store instead of in a second pass over the activation.
+    const float* oscale;    // [Cout] or null (1)
+    int relu;               // clamp at zero: on the accumulators without res, behind the residual add with it
     // Fused BatchNorm+ReLU backward prologue (data-gradient launches only).  The tensor this kernel
     // differentiates, a = relu(BN(bnx) [+ identity]), is the previous layer's activation; instead of
     // da the store loop writes dm = da·[a > 0] and accumulates Σdm, Σdm·x̂ per channel — the two
@@ -145,7 +150,9 @@ __device__ __forceinline__ void lds_read16(i32x4v& dst, unsigned addr) {
 #endif
 
 // Fragment reads are software-pipelined against the MFMAs by hand (see the K loop).
-template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64>
+// INFER: the evaluation epilogue (Conv2Args::oscale / relu) is compiled into its own instances — as run-time
+// branches of the one kernel it cost the TRAINING step 0.9 % (same-box A/B, profiles/r3_eval_forward_fused.md)
+template <int BM, int BN, int WGM, int WGN, int NST, int MINW, bool UNIT, int BK = 64, bool INFER = false>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2Args p) {
     constexpr int T = 64 * WGM * WGN;
     constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
@@ -428,13 +435,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
             for (int j = 0; j < 4; ++j)
                 if (n0 + col + j < p.Cout) b4[j] = p.bias[n0 + col + j];
         }
+        float sc4[INFER ? 4 : 1];
+        bool relu_acc = false;                                                        // uniform
+        if constexpr (INFER) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc4[j] = (p.oscale && n0 + col + j < p.Cout) ? p.oscale[n0 + col + j] : 1.f;
+            relu_acc = p.relu && p.res == nullptr;
+        }
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int row = wm * WTM + mi * 16 + l15;
             float v[4];
+            if constexpr (INFER) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + b4[j];
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaf(acc[mi][ni][j], sc4[j], b4[j]);
+                    v[j] = relu_acc ? fmaxf(v[j], 0.f) : v[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + b4[j];
+            }
             if (do_stats) {
                 // rows beyond M were fed zeros and there is no bias on this path: they add exactly 0
 #pragma unroll
@@ -533,6 +555,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv_igemm2_kernel(Conv2
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) a[j] += b[j];
+                        }
+                        if constexpr (INFER) {
+                            if (p.relu) {             // uniform: the block's ReLU behind the identity add
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j], 0.f);
+                            }
                         }
                         *reinterpret_cast<uint4*>(yout + (long)(m0 + row) * p.ldy + gcol) = pack8(a);
                     }
@@ -686,7 +714,23 @@ int launch2(Conv2Args& p, bool unit, hipStream_t st) {
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (p.w_img && p.img_px % BM != 0) return -2;          // a tile would straddle two images' weights
-    if (unit) {
+    if (p.oscale || p.relu) {
+        if (unit) {
+            auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK, true>;
+            if (lds > 64 * 1024) {
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+            }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
+        } else {
+            auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, false, BK, true>;
+            if (lds > 64 * 1024) {
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+            }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(T), lds, st, p);
+        }
+    } else if (unit) {
         auto kfn = conv_igemm2_kernel<BM, BN, WGM, WGN, NST, MINW, true, BK>;
         if (lds > 64 * 1024) {
             static bool once = false;
@@ -741,6 +785,8 @@ thread_local float t_mask_scale = 1.f;
 thread_local int t_ldx = 0;      // set by dp_conv_igemm2w
 thread_local const float* t_res_affine[2] = {nullptr, nullptr};   // set by dp_conv_igemm2ra
 thread_local int t_w_img = 0;    // set by dp_conv_igemm2pi
+thread_local const float* t_oscale = nullptr;   // set by dp_conv_igemm2e
+thread_local int t_relu = 0;
 int g_ablate = 0;
 #ifdef DP_STAMP
 unsigned long long* g_dbg = nullptr;
@@ -774,6 +820,8 @@ DP_EXPORT int dp_conv_igemm2r(const void* x, const void* w, void* y, const float
     p.res = (const bf16_raw*)res; p.ldres = ldres;
     p.res_scale = res ? t_res_affine[0] : nullptr; p.res_shift = res ? t_res_affine[1] : nullptr;
     if (p.res_scale && t_bnsums) return -1;
+    p.oscale = t_oscale; p.relu = t_relu;
+    if ((p.oscale || p.relu) && (stats || t_bnsums || p.res_scale)) return -1;
     p.bnx = (const bf16_raw*)t_bnx; p.bna = (const bf16_raw*)t_bna; p.bnsums = t_bnsums;
     p.bnmask = (const unsigned char*)t_bnmask;
     p.bn_mean = t_bnp[0]; p.bn_rstd = t_bnp[1]; p.bn_w = t_bnp[2]; p.bn_b = t_bnp[3];
@@ -849,6 +897,20 @@ DP_EXPORT int dp_conv_igemm2ra(const void* x, const void* w, void* y, int N, int
     const int rc = dp_conv_igemm2r(x, w, y, nullptr, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv,
                                    pad_h, pad_w, dil_h, dil_w, Cout, cfg, res, Cout, st);
     t_res_affine[0] = t_res_affine[1] = nullptr;
+    return rc;
+}
+
+// Inference: y = act(conv(x, w) * oscale + oshift [+ res]) with act = ReLU when `relu` (oscale / oshift: fp32 [Cout] or
+// null = 1 / 0; res: [N*Ho*Wo, ldres] bf16 or null).  The evaluation-mode BatchNorm + residual + ReLU of a block in the
+// convolution's own epilogue.
+DP_EXPORT int dp_conv_igemm2e(const void* x, const void* w, void* y, const float* oscale, const float* oshift, int relu,
+                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int R, int S, int smul,
+                              int sdiv, int pad_h, int pad_w, int dil_h, int dil_w, int ldy, int cfg,
+                              const void* res, int ldres, hipStream_t st) {
+    t_oscale = oscale; t_relu = relu ? 1 : 0;
+    const int rc = dp_conv_igemm2r(x, w, y, oshift, nullptr, 1, N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, smul, sdiv, pad_h,
+                                   pad_w, dil_h, dil_w, ldy, cfg, res, ldres, st);
+    t_oscale = nullptr; t_relu = 0;
     return rc;
 }
 

@@ -35,6 +35,8 @@ def _lib():
         lib.dp_conv_igemm2b.argtypes = [V, V, V] + [I] * 16 + [V] * 9 + [I, c_float, V]
         lib.dp_conv_igemm2ra.argtypes = [V, V, V] + [I] * 16 + [V] * 4
         lib.dp_conv_igemm2pi.argtypes = [V, V, V] + [I] * 6 + [V, V]
+        if hasattr(lib, "dp_conv_igemm2e"):          # (absent from an older library named by DPAMD_HIP_LIB in A/B runs)
+            lib.dp_conv_igemm2e.argtypes = [V] * 5 + [I] * 18 + [V, I, V]
         lib.dp_weight_transpose.argtypes = [V, V, I, I, I, I, V]
         lib.dp_weight_transpose_batched.argtypes = [V, V, V, I, I, V]
         lib.dp_conv_wgrad.argtypes = [V, V, V] + [I] * 16 + [V]
@@ -156,6 +158,57 @@ def igemm(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: 
         return _hip_bn.affine_add_(y, residual, residual_affine[0], residual_affine[1])
     if residual is not None:
         y += residual
+    return y
+
+
+def igemm_infer(x: torch.Tensor, w_krsc: torch.Tensor, out_hw: Tuple[int, int], smul: int, sdiv: int,
+                pad: Tuple[int, int], dil: Tuple[int, int], affine: Optional[torch.Tensor], relu: bool,
+                residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """``act(conv(x, w) * scale + shift [+ residual])`` in ONE launch (csrc/conv_igemm2.hip, ``dp_conv_igemm2e``): the
+    evaluation-mode BatchNorm (``affine``: contiguous fp32 [2, Cout] = scale | shift, or None), the identity add and
+    the ReLU of a block leave with the convolution's store.  Inference only (no autograd node).  Returns None for a
+    shape the second-generation kernel does not take — the caller then runs convolution and BatchNorm separately."""
+    n, cin, hi, wi = x.shape
+    cout, cin_w, r, s = w_krsc.shape
+    ho, wo = out_hw
+    if (x.dtype != torch.bfloat16 or w_krsc.dtype != torch.bfloat16 or cin != cin_w or cin % 8 or cout % 8 or r * s > 32
+            or not x.is_contiguous(memory_format=torch.channels_last) or not w_krsc.permute(0, 2, 3, 1).is_contiguous()
+            or x.numel() * 2 >= _OFFSET_LIMIT or w_krsc.numel() * 2 >= _OFFSET_LIMIT or n * ho * wo >= (1 << 31) - 512):
+        return None
+    if affine is not None and (affine.dtype != torch.float32 or tuple(affine.shape) != (2, cout)
+                               or not affine.is_contiguous() or affine.device != x.device):
+        raise ValueError("igemm_infer: affine must be contiguous fp32 [2, Cout] on the input's device")
+    if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (n, cout, ho, wo)
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)
+                                 or residual.data_ptr() % 16):
+        return None
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    # a tile of the second generation (the first-generation kernel, candidate 0 of the training entries, has no such
+    # epilogue): the training entry of the same problem when it names one, else measured among them
+    key = (n, hi, wi, cin, ho, wo, cout, r, s, smul, sdiv, pad, dil, True, False)
+    cfg = _FORCED_CFG if _FORCED_CFG is not None else _TUNED.get(key)
+    if cfg is not None and cfg <= 0:
+        key = key + ("infer",)
+        cfg = _TUNED.get(key)
+    if cfg is None:
+        if B.deterministic() or not _AUTOTUNE:
+            cfg = 1
+        else:
+            shift = affine[1] if affine is not None else torch.zeros(cout, dtype=torch.float32, device=x.device)
+            args = (B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(shift), B.ptr(None), 1, n, hi, wi, cin, ho, wo, cout, r, s, smul,
+                    sdiv, pad[0], pad[1], dil[0], dil[1], cout)
+            cfg = _TUNED[key] = _agreed(lambda: _autotune(args, None, 1, cout, x.device,
+                                                          candidates=[c for c in _CANDIDATES if c > 0]))
+            _save_tuned()
+    if cfg <= 0:
+        return None
+    st = _lib().dp_conv_igemm2e(B.ptr(x), B.ptr(w_krsc), B.ptr(y), B.ptr(affine[0]) if affine is not None else None,
+                                B.ptr(affine[1]) if affine is not None else None, int(bool(relu)), n, hi, wi, cin, ho, wo,
+                                cout, r, s, smul, sdiv, pad[0], pad[1], dil[0], dil[1], cout, cfg, B.ptr(residual), cout,
+                                B.stream_ptr())
+    if st in (-2, -4):
+        return None
+    B.check(st, "conv_igemm2e")
     return y
 
 

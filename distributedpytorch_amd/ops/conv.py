@@ -142,6 +142,20 @@ class Conv2d(nn.Module):
         return s
 
 
+INFER_FUSE = True         # (module switch for tests / tools: False = convolution and evaluation BatchNorm as two passes)
+
+
+def _infer_fused(conv: "Conv2d", bn, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor]):
+    from . import _hip_conv
+    n, _, hi, wi = x.shape
+    r, s = conv.kernel_size
+    ho = _hip_conv._out_size(hi, r, conv.stride[0], conv.padding[0], conv.dilation[0])
+    wo = _hip_conv._out_size(wi, s, conv.stride[1], conv.padding[1], conv.dilation[1])
+    res = _hip_conv.as_nhwc(residual) if residual is not None else None
+    return _hip_conv.igemm_infer(_hip_conv.as_nhwc(x), conv.lowp_weight(x.dtype), (ho, wo), conv.stride[0], 1,
+                                 tuple(conv.padding), tuple(conv.dilation), bn.eval_affine(), relu, res)
+
+
 def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
                 residual: Optional[torch.Tensor] = None, passthrough: bool = False, sole_consumer: bool = False,
                 dropout: float = 0.0, out=None):
@@ -158,6 +172,13 @@ def conv_bn_act(conv: "Conv2d", bn, x: torch.Tensor, relu: bool = False,
     autograd node: use ``x'`` as the block's identity and the skip-path gradient is added inside the
     data-gradient kernel (csrc/conv_igemm2.hip store loop) instead of by an add kernel."""
     slot = out
+    if (INFER_FUSE and not bn.training and slot is None and not torch.is_grad_enabled() and B.use_hip(x)
+            and x.dtype == torch.bfloat16 and conv.groups == 1 and conv.bias is None
+            and conv.stride[0] == conv.stride[1] and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0):
+        # evaluation: BatchNorm (running statistics), identity add and ReLU in the convolution's epilogue
+        y = _infer_fused(conv, bn, x, relu, residual)
+        if y is not None:
+            return (y, x) if passthrough else y
     pt = passthrough and conv.can_passthrough(x)
     if bn.training and not bn.frozen and conv.can_fuse_stats(x):
         if pt:

@@ -26,6 +26,8 @@ class GraphedForward:
         self._graphs: Dict[Tuple, tuple] = {}
         from ..ops.conv import Conv2d
         self._convs = [m for m in model.modules() if isinstance(m, Conv2d)]
+        from ..ops.batchnorm import BatchNorm2d
+        self._bns = [m for m in model.modules() if isinstance(m, BatchNorm2d)]
 
     def _capture(self, x: torch.Tensor):
         static_in = x.clone()
@@ -54,6 +56,8 @@ class GraphedForward:
         # the bf16 weight copies are refreshed IN PLACE outside the graph when a master weight changed
         for m in self._convs:
             m.lowp_weight(x.dtype)
+        for m in self._bns:        # the (scale | shift) blocks of the running statistics, same storage (ops.batchnorm)
+            m.eval_affine()
         static_in.copy_(x)
         graph.replay()
         return static_out      # valid until the next call with the same shape

@@ -112,9 +112,9 @@ def parse_args(argv=None):
                     help="replay the training step from one hipGraph per input shape (one rank, no accumulation): the "
                          "small-batch regime, where the host's ~900 launches per step are the bound")
     ap.add_argument("--graph-eval", choices=["auto", "on", "off"], default="auto",
-                    help="semantic-task validation: replay the forward from a hipGraph per batch shape.  auto: on the GPU "
-                         "when testBatch <= 4 (the reference's testBatch = 1 is launch-bound: 120 -> 261 img/s) or with "
-                         "--graph-step")
+                    help="validation: replay the forward from a hipGraph per batch shape.  auto: with --graph-step, and "
+                         "for the semantic task on the GPU when testBatch <= 4 (the reference's testBatch = 1 is "
+                         "launch-bound: 234 -> 310 img/s)")
     ap.add_argument("--finite-every", type=int, default=50, help="steps between host reads of the device-side "
                     "non-finite-loss flag")
     ap.add_argument("--on-nonfinite", choices=["abort", "restore"], default="abort",
@@ -231,7 +231,12 @@ def _graph_eval(args) -> bool:
     mode = getattr(args, "graph_eval", "auto")               # (callers outside main() pass their own namespace)
     if mode != "auto":
         return mode == "on"
-    return bool(getattr(args, "graph_step", False)) or getattr(args, "testBatch", 1) <= 4
+    if getattr(args, "graph_step", False):
+        return True
+    # semantic task: the batch-1 forward is still bound by its launches (R101: 2.9 ms eager, 2.3 ms replayed); the
+    # instance task's DANet forward at batch 1 is bound by the device since the evaluation epilogue (145 img/s eager,
+    # 129 replayed: profiles/r3_eval_forward_fused.md)
+    return getattr(args, "task", "semseg") != "instance" and getattr(args, "testBatch", 1) <= 4
 
 
 def _memory_report(engine) -> dict:
