@@ -62,7 +62,12 @@ class _Base:
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.dtype = torch.bfloat16 if self.on_gpu else torch.float32
-        self.model = model.to(self.device).to(memory_format=torch.channels_last).eval()
+        if any(hasattr(p, "_dpamd_grad_sink") for p in model.parameters()):
+            # a TrainEngine's model: its parameters are views of the engine's arena, already on the device and in the
+            # kernels' layout — moving or re-laying them out would cut them loose from it
+            self.model = model.eval()
+        else:
+            self.model = model.to(self.device).to(memory_format=torch.channels_last).eval()
         self._fwd = self.model
         if graph and self.on_gpu:
             from .parallel.graphs import GraphedForward

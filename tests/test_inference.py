@@ -130,3 +130,23 @@ def test_predict_cli_writes_paletted_maps(tmp_path):
                         "--no-write"])
     assert rec["steady"] and rec["forward_img_per_s"] > 0 and rec["output"] is None
     json.dumps(rec)
+
+
+def test_predictor_over_a_training_engines_model_leaves_the_arena_intact():
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy
+    from distributedpytorch_amd.parallel import TrainEngine
+    torch.manual_seed(4)
+    engine = TrainEngine(build_model("fcn_resnet18", 5), SoftmaxCrossEntropy(255), lr=0.05, momentum=0.9, weight_decay=0.0,
+                         device=torch.device("cpu"))
+    ptrs = [p.data_ptr() for p in engine.model.parameters()]
+    pred = SemSegPredictor(engine.model, "cpu", crop=65, batch=2)
+    img = np.random.default_rng(4).integers(0, 256, (50, 60, 3), dtype=np.uint8)
+    before = pred.logits([img])[0].clone()
+    assert ptrs == [p.data_ptr() for p in engine.model.parameters()]
+    engine.model.train()
+    x, y = torch.randn(2, 3, 65, 65), torch.randint(0, 5, (2, 65, 65))
+    for _ in range(2):
+        engine.train_step(x, y)
+    engine.model.eval()
+    after = pred.logits([img])[0]
+    assert not torch.allclose(before, after)                      # the predictor sees the trained weights and statistics
