@@ -43,6 +43,23 @@ class SeparableConv2d(nn.Module):
     def depthwise_bn(self, x):
         return conv_bn_act(self.conv1, self.bn, x)
 
+    # evaluation constants (ops.sepconv.eval_fold_constants): stale after a switch of mode, a loaded state dict, a move
+    def train(self, mode: bool = True):
+        self.__dict__["_eval_fold_epoch"] = self.__dict__.get("_eval_fold_epoch", 0) + 1
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kw):
+        self.__dict__["_eval_fold_epoch"] = self.__dict__.get("_eval_fold_epoch", 0) + 1
+        return super()._load_from_state_dict(*args, **kw)
+
+    def _apply(self, fn, *args, **kw):
+        self.__dict__.pop("_eval_fold", None)
+        return super()._apply(fn, *args, **kw)
+
+    def eval_refresh(self):
+        from ..ops.sepconv import eval_fold_constants
+        eval_fold_constants(self)
+
     def forward(self, x):
         return self.pointwise(self.depthwise_bn(x))
 

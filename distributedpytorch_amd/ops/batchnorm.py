@@ -453,6 +453,9 @@ class BatchNorm2d(nn.Module):
             self._affine_key = key
         return a
 
+    def eval_refresh(self):
+        self.eval_affine()
+
     def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
                 stats: Optional[torch.Tensor] = None, dropout: float = 0.0, out=None):
         """``dropout``: probability of a dropout behind the activation, applied in training mode only

@@ -163,6 +163,47 @@ def can_fold(sep, bn2, x: torch.Tensor) -> bool:
             and pw.in_channels % 8 == 0 and pw.out_channels % 8 == 0 and pw.in_channels <= 8192)
 
 
+EVAL_FOLD = True          # (module switch for tests / tools)
+
+
+def _eval_fold_ok(sep, bn2, x: torch.Tensor) -> bool:
+    pw = sep.pointwise
+    return (EVAL_FOLD and not bn2.training and not sep.bn.training and not torch.is_grad_enabled() and B.use_hip(x)
+            and x.dtype == torch.bfloat16 and pw.bias is None and pw.groups == 1 and pw.kernel_size == (1, 1)
+            and pw.stride == (1, 1) and pw.padding == (0, 0) and pw.in_channels % 8 == 0 and pw.out_channels % 8 == 0)
+
+
+@torch.no_grad()
+def eval_fold_constants(sep, bn2=None):
+    """Evaluation constants of a separable unit: with running statistics BN1 is a per-channel affine map between two
+    linear maps, so ``BN2(pointwise(BN1(z))) = (W diag(s1)) z * s2 + (s2 * (W t1) + t2)`` — the pointwise weights with
+    BN1's scale folded in (bf16, the layout of the kernels' weights) and one (scale | shift) block for the
+    convolution's evaluation epilogue; the pass of BN1 over the depthwise output is gone.  Computed once per
+    evaluation phase INTO FIXED STORAGE (captured graphs keep reading it; ``parallel.graphs`` calls
+    ``sep.eval_refresh()`` before a replay); stale after what makes ``BatchNorm2d.eval_affine`` stale."""
+    st = sep.__dict__.get("_eval_fold")
+    if bn2 is None:
+        if st is None:
+            return None
+        bn2 = st["bn2"]
+    pw, bn1 = sep.pointwise, sep.bn
+    a1, a2 = bn1.eval_affine(), bn2.eval_affine()
+    key = (pw.weight._version, bn1._affine_key, bn2._affine_key, sep.__dict__.get("_eval_fold_epoch", 0))
+    dev = pw.weight.device
+    if st is None or st["bn2"] is not bn2 or st["w"].device != dev:
+        st = {"bn2": bn2, "key": None,
+              "w": torch.empty(pw.weight.shape, dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last),
+              "aff": torch.empty(2, pw.out_channels, dtype=torch.float32, device=dev)}
+        sep.__dict__["_eval_fold"] = st
+    if st["key"] != key:
+        w = pw.weight.detach().float()
+        st["w"].copy_(w * a1[0].view(1, -1, 1, 1))
+        st["aff"][0].copy_(a2[0])
+        st["aff"][1].copy_(a2[0] * (w.flatten(1) @ a1[1]) + a2[1])
+        st["key"] = key
+    return st
+
+
 def sepconv_bn_act(sep, bn2, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
                    dropout: float = 0.0, passthrough: bool = False, sole_consumer: bool = False):
     """``act(BN2(pointwise(BN1(depthwise(x)))) + residual)`` for a ``models.xception.SeparableConv2d`` ``sep``.
@@ -174,6 +215,15 @@ def sepconv_bn_act(sep, bn2, x: torch.Tensor, relu: bool = False, residual: Opti
     ``sole_consumer``: ``x`` (a fused BN+ReLU output) feeds nothing but this unit (and its passthrough), so that
     BatchNorm's backward reductions run in the same kernel's epilogue."""
     dw = sep.conv1
+    if _eval_fold_ok(sep, bn2, x):
+        from . import _hip_conv
+        st = eval_fold_constants(sep, bn2)
+        z = _hip_conv.as_nhwc(dw(x))
+        res = _hip_conv.as_nhwc(residual) if residual is not None else None
+        y = _hip_conv.igemm_infer(z, st["w"], tuple(z.shape[2:]), 1, 1, (0, 0), (1, 1), st["aff"], relu, res)
+        if y is None:            # (a shape the kernel does not take: BN1 as its own pass after all)
+            y = conv_bn_act(sep.pointwise, bn2, sep.bn(z), relu=relu, residual=residual)
+        return (y, x) if passthrough else y
     pt = passthrough and dw.can_passthrough(x)
     if not can_fold(sep, bn2, x):
         if bn2.training and not sep.bn.frozen and dw.can_fuse_stats(x) and (pt or sole_consumer) and sep.bn.training:

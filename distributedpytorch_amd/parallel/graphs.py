@@ -26,8 +26,9 @@ class GraphedForward:
         self._graphs: Dict[Tuple, tuple] = {}
         from ..ops.conv import Conv2d
         self._convs = [m for m in model.modules() if isinstance(m, Conv2d)]
-        from ..ops.batchnorm import BatchNorm2d
-        self._bns = [m for m in model.modules() if isinstance(m, BatchNorm2d)]
+        # modules with constants of the evaluation phase held in fixed storage (BatchNorm's scale | shift blocks, the
+        # folded weights of Xception's separable units)
+        self._consts = [m for m in model.modules() if hasattr(m, "eval_refresh")]
 
     def _capture(self, x: torch.Tensor):
         static_in = x.clone()
@@ -56,8 +57,8 @@ class GraphedForward:
         # the bf16 weight copies are refreshed IN PLACE outside the graph when a master weight changed
         for m in self._convs:
             m.lowp_weight(x.dtype)
-        for m in self._bns:        # the (scale | shift) blocks of the running statistics, same storage (ops.batchnorm)
-            m.eval_affine()
+        for m in self._consts:     # same storage, refreshed when stale (ops.batchnorm, ops.sepconv)
+            m.eval_refresh()
         static_in.copy_(x)
         graph.replay()
         return static_out      # valid until the next call with the same shape

@@ -139,14 +139,15 @@ def test_inference_epilogue_matches_fp32(case):
         assert float(y.min()) >= 0.0
 
 
-def test_eval_forward_fused_equals_two_pass_and_follows_the_weights():
+@pytest.mark.parametrize("name", ["deeplabv3plus_resnet50", "deeplabv3plus_xception65"])
+def test_eval_forward_fused_equals_two_pass_and_follows_the_weights(name):
     """The fused evaluation path against convolution + BatchNorm as two passes; and the cached (scale | shift) blocks
     follow a training step, a loaded state dict and an in-place edit — through an already captured graph too."""
-    from distributedpytorch_amd.ops import SoftmaxCrossEntropy, conv as conv_mod
+    from distributedpytorch_amd.ops import SoftmaxCrossEntropy, conv as conv_mod, sepconv as sep_mod
     from distributedpytorch_amd.parallel import GraphedForward, TrainEngine
     torch.manual_seed(0)
     from distributedpytorch_amd.models import build_model
-    model = build_model("deeplabv3plus_resnet50", 21)
+    model = build_model(name, 21)
     engine = TrainEngine(model, SoftmaxCrossEntropy(255), lr=0.01, momentum=0.9, weight_decay=1e-4, device=torch.device("cuda", 0))
     g = torch.Generator().manual_seed(1)
     xs = torch.randn(4, 3, 129, 129, generator=g)
@@ -155,7 +156,7 @@ def test_eval_forward_fused_equals_two_pass_and_follows_the_weights():
     graphed = GraphedForward(engine.model)
 
     def two_pass():
-        conv_mod.INFER_FUSE = False
+        conv_mod.INFER_FUSE = sep_mod.EVAL_FOLD = False
         try:
             with torch.no_grad():
                 for m in engine.model.modules():               # (fresh blocks: this is the reference)
@@ -163,7 +164,7 @@ def test_eval_forward_fused_equals_two_pass_and_follows_the_weights():
                         m._affine_key = None
                 return engine.model(x_eval).float().clone()
         finally:
-            conv_mod.INFER_FUSE = True
+            conv_mod.INFER_FUSE = sep_mod.EVAL_FOLD = True
 
     def check(tag):
         engine.model.eval()
