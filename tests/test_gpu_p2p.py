@@ -102,7 +102,12 @@ def _engine_worker(rank, world, port, sync_bn):
     parallel.debug check on: bucket order, identical gradients after the all-reduce, identical
     replicas.  (Regression: gradient hooks counted twice emptied the bucket counters early.)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", DPAMD_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", DPAMD_DIST_BACKEND="gloo",
+                      DPAMD_P2P_TIMEOUT_MS="4000")
+    # a rank that is still here after 90 s says where it is (every thread's stack on stderr) and exits: the full GPU
+    # suite once stopped in this test for its whole 120 s limit and the parent's stack was all the log held
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
     from distributedpytorch_amd.models import build_model
     from distributedpytorch_amd.ops import SoftmaxCrossEntropy
     from distributedpytorch_amd.parallel import TrainEngine, debug, dist_env, init_distributed, p2p
@@ -124,6 +129,7 @@ def _engine_worker(rank, world, port, sync_bn):
         other = flat.clone()
         dist.broadcast(other, src=0)
         assert torch.equal(flat, other), "replicas diverged"
+        faulthandler.cancel_dump_traceback_later()
     finally:
         if p2p._default is not None:
             p2p._default.close()
