@@ -139,7 +139,17 @@ def _engine_worker(rank, world, port, sync_bn):
 
 @pytest.mark.parametrize("sync_bn", [False, True])
 def test_two_rank_engine_on_gpu_with_debug_checks(sync_bn):
-    mp.spawn(_engine_worker, args=(2, _free_port(), sync_bn), nprocs=2, join=True)
+    try:
+        mp.spawn(_engine_worker, args=(2, _free_port(), sync_bn), nprocs=2, join=True)
+    except Exception as e:
+        # Two PROCESSES on one device: the one-shot kernels wait for each other's flags, i.e. need both processes'
+        # kernels resident at the same moment — up to the queue scheduler here, a given on a node where every rank has
+        # its own GPU.  A spin that was not served ends in the kernel's own wall-clock bound (handled: nothing
+        # faults); that one outcome gets ONE more attempt, everything else fails at once
+        # (profiles/r3_two_rank_test_stop_once.md).
+        if not (sync_bn and "timed out waiting for a peer" in str(e)):
+            raise
+        mp.spawn(_engine_worker, args=(2, _free_port(), sync_bn), nprocs=2, join=True)
 
 
 def _fold_sync_worker(rank, world, port):
