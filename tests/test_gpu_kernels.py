@@ -437,7 +437,8 @@ def test_upsample_ce_fused(c, hin, hout, padded):
     assert float(lz) == 0.0 and float(xh.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("c,hin,hout", [(256, 33, 129), (21, 129, 513), (48, 17, 65), (21, 33, 20), (64, 1, 9)])
+@pytest.mark.parametrize("c,hin,hout", [(256, 33, 129), (21, 129, 513), (48, 17, 65), (21, 33, 20), (64, 1, 9), (1, 65, 513),
+                                          (3, 9, 40), (5, 20, 301)])
 def test_bilinear(c, hin, hout):
     torch.manual_seed(5)
     x = _bf(torch.randn(2, c, hin, hin, device=DEV))
