@@ -13,7 +13,8 @@
 //
 // Slots are double-buffered by call parity: a rank can enter call k+2 (and overwrite slot k%2 of a
 // peer) only after that peer's call k+1 granules arrived, i.e. after the peer finished reading call k.
-// Every spin is bounded by the wall clock; a timeout raises an error word instead of hanging the GPU.
+// Every spin is bounded by the wall clock; a timeout raises an error word instead of hanging the GPU, and calls that
+// find the word set return at once (one bound per lost peer, not one per call).
 #include "common.h"
 
 namespace {
@@ -32,6 +33,9 @@ struct P2PArgs {
 
 // receive buffer layout (per rank): [2 slots][world sources][maxn granules]
 __global__ __launch_bounds__(kThreadsP2P) void p2p_allreduce_kernel(P2PArgs a) {
+    // A peer was lost in an earlier call (its spin ran into the bound): the step's numbers are void already and the
+    // host raises at its next check — do not wait the bound out again in each of the ~200 calls that follow.
+    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const size_t slot_off = (size_t)(a.seq & 1u) * a.world * a.maxn;
     const int stride = gridDim.x * blockDim.x;
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x;

@@ -32,6 +32,11 @@ def _spread(value: float, device) -> float:
     """max − min of ``value`` over the ranks (0 when they agree)."""
     if _world() == 1:
         return 0.0
+    # a HOST value: over gloo it travels as a host tensor whatever device the caller names — gloo's device-tensor path
+    # (stage through the stream, reduce, copy back) stalled about once in ten two-rank runs sharing one GPU, both ranks
+    # inside this very all-reduce (profiles/r3_two_rank_test_stop_once.md)
+    if not (dist.get_backend() == "nccl"):
+        device = torch.device("cpu")
     t = torch.tensor([value, -value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0].item() + t[1].item())

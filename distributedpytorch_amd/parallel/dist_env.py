@@ -154,8 +154,9 @@ def broadcast_int(value: int, src: int = 0) -> int:
 def all_reduce_scalar(value: float, op: str = "sum", device: Optional[torch.device] = None) -> float:
     if get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64,
-                     device=device if device is not None else _default_device())
+    if device is None or dist.get_backend() != "nccl":
+        device = _default_device()          # (gloo: a host tensor whatever the caller names, see _stage_through_host)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
     return float(t.item())
 

@@ -285,7 +285,7 @@ class TrainEngine:
         if dist_env.get_world_size() > 1:
             import torch.distributed as dist
             packed = torch.cat([cm.view(-1).double(), loss_sum.view(1), loss_sum.new_tensor([float(n)])])
-            dist.all_reduce(packed)
+            dist_env.all_reduce_(packed)         # (host-staged under gloo)
             cm = packed[:-2].view(num_classes, num_classes).round().long()
             loss_sum, n = packed[-2], float(packed[-1].item())
         miou, iou, acc = miou_from_confusion(cm)

@@ -198,7 +198,7 @@ def resolve() -> bool:
             import sys
             print(f"[dpamd] one-shot SyncBN all-reduce unavailable ({e}); using RCCL all-reduces", file=sys.stderr)
         inst = None
-    flag = torch.tensor([passed], device="cuda")
+    flag = torch.tensor([passed], device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # everyone switches, or nobody does
     ENABLED = bool(flag.item() > 0.5)
     if ENABLED:

@@ -86,6 +86,27 @@ def _worker(rank, world, port, sync_bn_case):
             y2r = ops.conv_bn_act(conv, bn2_ref, xr.detach(), relu=True)
             assert torch.allclose(y2.float(), y2r[2 * rank:2 * rank + 2].float(), atol=3e-2, rtol=3e-2)
         ar.check()
+        if world == 2:
+            # a peer that never arrives: ONE wall-clock bound, the error word raised at the next check, and the calls
+            # that follow return at once (a step has ~200 of them) instead of waiting the bound out again each
+            import time
+            dist.barrier()
+            if rank == 0:
+                t = torch.ones(64, device="cuda")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ar.all_reduce_(t, timeout_ms=300)
+                torch.cuda.synchronize()
+                first = time.perf_counter() - t0
+                with pytest.raises(RuntimeError, match="timed out waiting for a peer"):
+                    ar.check()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    ar.all_reduce_(t, timeout_ms=300)
+                torch.cuda.synchronize()
+                later = time.perf_counter() - t0
+                assert 0.25 < first < 5.0 and later < 0.25, (first, later)
+            dist.barrier()
     finally:
         ar.close()
         dist.destroy_process_group()
@@ -145,8 +166,9 @@ def test_two_rank_engine_on_gpu_with_debug_checks(sync_bn):
         # Two PROCESSES on one device: the one-shot kernels wait for each other's flags, i.e. need both processes'
         # kernels resident at the same moment — up to the queue scheduler here, a given on a node where every rank has
         # its own GPU.  A spin that was not served ends in the kernel's own wall-clock bound (handled: nothing
-        # faults); that one outcome gets ONE more attempt, everything else fails at once
-        # (profiles/r3_two_rank_test_stop_once.md).
+        # faults); that one outcome gets ONE more attempt, everything else fails at once.  (Never seen so far: the
+        # stop this was first written for turned out to be gloo's device-tensor path in a debug check,
+        # profiles/r3_two_rank_test_stop_once.md.)
         if not (sync_bn and "timed out waiting for a peer" in str(e)):
             raise
         mp.spawn(_engine_worker, args=(2, _free_port(), sync_bn), nprocs=2, join=True)

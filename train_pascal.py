@@ -414,8 +414,7 @@ def validate_instance_device(engine, loader, args, epoch=0, fig_path=None, tick=
             save_validation_panels(fig_path, x[0].float().cpu(), y[0, 0].float().cpu(),
                                    [o[0].float().cpu() for o in outs], epoch)
     if dist_env.get_world_size() > 1:
-        import torch.distributed as dist
-        dist.all_reduce(acc)
+        dist_env.all_reduce_(acc)            # (host-staged under gloo: its device-tensor path stalls with shared GPUs)
     tot = acc.tolist()                                               # the epoch's one host read
     cnt = max(tot[4], 1.0)
     dt = max(timeit.default_timer() - t0, 1e-9)
