@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--no-write", action="store_true", help="skip the PNG files (rate runs)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="N > 1: one process per GPU (started here, or ranks of torchrun), the images dealt round-robin; "
+                         "rank 0 prints the job's total rate")
     return ap.parse_args(argv)
 
 
@@ -89,6 +92,11 @@ def _points_for(args, files):
 
 def main(argv=None):
     args = parse_args(argv)
+    # one command, N GPUs: the parent starts the ranks BEFORE anything touches the GPU (parallel.launch)
+    from distributedpytorch_amd.parallel.launch import maybe_self_launch
+    status = maybe_self_launch(args.gpus, argv=argv, script=os.path.abspath(__file__), cpu=args.cpu)
+    if status is not None:
+        sys.exit(status)
     import numpy as np
     import torch
     from PIL import Image
@@ -97,13 +105,21 @@ def main(argv=None):
     instance = args.task == "instance"
     name = args.model or ("danet_resnet101" if instance else "deeplabv3plus_resnet101")
     crop = args.crop or (512 if instance else 513)
-    device = torch.device("cpu") if args.cpu or not torch.cuda.is_available() else torch.device("cuda", 0)
+    rank, world = 0, 1
+    if args.gpus > 1:
+        from distributedpytorch_amd.parallel import dist_env, init_distributed
+        info = init_distributed(device="cpu" if args.cpu else None)
+        if info.world_size != args.gpus:
+            raise SystemExit(f"[predict] --gpus {args.gpus} but the job has WORLD_SIZE={info.world_size}")
+        rank, world, device = info.rank, info.world_size, info.device
+    else:
+        device = torch.device("cpu") if args.cpu or not torch.cuda.is_available() else torch.device("cuda", 0)
     kw = dict(crop=crop, batch=args.batch, graph=not args.no_graph)
     if not instance:
         kw["fit"] = args.fit
     torch.manual_seed(0)
     pred = load_predictor(args.task, name, args.weights, args.num_classes, args.output_stride, device, **kw)
-    if not args.weights:
+    if not args.weights and rank == 0:
         print("[predict] no --weights: random initialisation (the rate is real, the labels are noise)", file=sys.stderr)
 
     if args.synthetic:
@@ -121,11 +137,24 @@ def main(argv=None):
         if not args.input:
             raise SystemExit("give --input (or --synthetic N)")
         files = _list_inputs(args.input)
+        points = _points_for(args, files) if instance else None
+        n_files = len(files)
+        if world > 1:            # this rank's share, dealt before anything is decoded: every world-th file
+            files, points = files[rank::world], (points[rank::world] if points is not None else None)
         images = [np.asarray(Image.open(f).convert("RGB"), dtype=np.uint8) for f in files]
         names = [os.path.splitext(os.path.basename(f))[0] for f in files]
-        points = _points_for(args, files) if instance else None
+
+    if args.synthetic:
+        n_total = len(images)
+        if world > 1:
+            images, names = images[rank::world], names[rank::world]
+            points = points[rank::world] if points is not None else None
+    else:
+        n_total = n_files
 
     def run():
+        if not images:
+            return []
         if instance:
             return pred.predict(images, points)
         return pred.predict(images)
@@ -153,10 +182,19 @@ def main(argv=None):
                 im = Image.fromarray(r, mode="P")
                 im.putpalette(pal)
                 im.save(os.path.join(args.output, nm + ".png"))
-    rec = {"task": args.task, "model": name, "images": len(images), "batch": args.batch, "crop": crop,
+    if world > 1:
+        # the job's rate: all images over the slowest rank's time
+        t_first = dist_env.all_reduce_scalar(t_first, "max", device if device.type == "cuda" else None)
+        if t_steady is not None:
+            t_steady = dist_env.all_reduce_scalar(t_steady, "max", device if device.type == "cuda" else None)
+        dist_env.barrier()
+        dist_env.shutdown()
+        if rank != 0:
+            return None
+    rec = {"task": args.task, "model": name, "images": n_total, "n_gpus": world, "batch": args.batch, "crop": crop,
            "device": str(device), "graph": bool(not args.no_graph and device.type == "cuda"),
            "first_pass_s": round(t_first, 3),
-           "forward_img_per_s": round(len(images) / (t_steady if t_steady is not None else t_first), 2),
+           "forward_img_per_s": round(n_total / (t_steady if t_steady is not None else t_first), 2),
            "steady": t_steady is not None, "output": None if args.no_write else args.output}
     print(json.dumps(rec), flush=True)
     return rec

@@ -195,3 +195,21 @@ def test_eval_forward_fused_equals_two_pass_and_follows_the_weights(name):
                 m.running_mean.add_(0.05)                       # an in-place edit while in evaluation mode
     d = check("after an in-place edit")
     assert _cos(c, d) < 0.9999
+
+
+def test_predict_cli_two_ranks_sharing_the_gpu(tmp_path):
+    """`predict.py --gpus 2` as the script starts it (two processes on the box's one GPU, gloo rendezvous): the images are
+    dealt between the ranks, every map is written once, rank 0 prints the job's line."""
+    import json
+    import subprocess
+    env = dict(os.environ, DPAMD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = tmp_path / "o"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "predict.py"), "--model", "deeplabv3plus_resnet50", "--crop", "257",
+                        "--synthetic", "10", "--synthetic-size", "120x200", "--batch", "4", "--gpus", "2", "--output", str(out)],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["images"] == 10 and rec["n_gpus"] == 2 and rec["graph"] is True
+    assert len(os.listdir(out)) == 10

@@ -150,3 +150,32 @@ def test_predictor_over_a_training_engines_model_leaves_the_arena_intact():
     engine.model.eval()
     after = pred.logits([img])[0]
     assert not torch.allclose(before, after)                      # the predictor sees the trained weights and statistics
+
+
+def test_predict_cli_two_ranks_deal_the_images(tmp_path):
+    """`predict.py --gpus 2` (here: two CPU ranks over gloo, started by the script itself): every image is written
+    exactly once, the maps equal the one-process run's, rank 0 prints the job's line."""
+    import subprocess
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    src = tmp_path / "in"
+    src.mkdir()
+    for i, (h, w) in enumerate([(50, 70), (64, 40), (33, 91), (80, 80), (45, 52)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(src / f"im{i}.png")
+    base = [sys.executable, os.path.join(ROOT, "predict.py"), "--cpu", "--model", "fcn_resnet18", "--crop", "65",
+            "--input", str(src), "--batch", "2"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    one = subprocess.run(base + ["--output", str(tmp_path / "one")], capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(base + ["--output", str(tmp_path / "two"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["images"] == 5 and rec["n_gpus"] == 2
+    assert sorted(os.listdir(tmp_path / "two")) == sorted(os.listdir(tmp_path / "one")) == [f"im{i}.png" for i in range(5)]
+    for i in range(5):
+        a = np.asarray(Image.open(tmp_path / "one" / f"im{i}.png"))
+        b = np.asarray(Image.open(tmp_path / "two" / f"im{i}.png"))
+        assert (a == b).mean() > 0.999
