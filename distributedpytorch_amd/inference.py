@@ -216,6 +216,31 @@ class InstancePredictor(_Base):
         nellipse_guidance_(x, self._h2d(pc), 3, self.alpha)
         return x, cb, sizes
 
+    def _paste_back_device(self, prob: torch.Tensor, cb: np.ndarray, sizes: np.ndarray) -> List[np.ndarray]:
+        """``helpers.crop2fullmask`` on the device: the crop-sized probabilities resized (bicubic, pixel centres, the
+        a = -0.75 kernel of the host form) to their relaxed boxes, the relax border suppressed, the part inside the image
+        written into a canvas of the image's size; results leave through pinned memory, one synchronisation."""
+        out = []
+        for i in range(prob.shape[0]):
+            h, w = int(sizes[i][0]), int(sizes[i][1])
+            x0, y0, x1, y1 = (int(v) for v in cb[i])
+            bh, bw = y1 - y0 + 1, x1 - x0 + 1
+            full = torch.zeros((h, w), dtype=torch.float32, device=self.device)
+            vx0, vy0, vx1, vy1 = max(x0, 0), max(y0, 0), min(x1, w - 1), min(y1, h - 1)
+            if bh > 0 and bw > 0 and vx1 >= vx0 and vy1 >= vy0:
+                c = F.interpolate(prob[i][None, None], size=(bh, bw), mode="bicubic", align_corners=False)[0, 0]
+                r = self.relax
+                if r > 0:
+                    keep = torch.zeros_like(c)
+                    keep[r:bh - r, r:bw - r] = 1.0
+                    c = c * keep
+                full[vy0:vy1 + 1, vx0:vx1 + 1] = c[vy0 - y0:vy1 - y0 + 1, vx0 - x0:vx1 - x0 + 1]
+            host = torch.empty((h, w), dtype=torch.float32, pin_memory=True)
+            host.copy_(full.clamp_(0.0, 1.0), non_blocking=True)
+            out.append(host)
+        torch.cuda.current_stream(self.device).synchronize()
+        return [t.numpy() for t in out]
+
     @torch.no_grad()
     def predict(self, images: Sequence[np.ndarray], points) -> List[np.ndarray]:
         from .data import helpers
@@ -227,6 +252,9 @@ class InstancePredictor(_Base):
             if self.on_gpu and n < self.batch and s0 > 0:
                 chunk, cp = chunk + [chunk[-1]] * (self.batch - n), np.concatenate([cp, np.repeat(cp[-1:], self.batch - n, 0)])
             x, cb, sizes = self.network_input(chunk, cp)
+            if self.on_gpu:
+                res.extend(self._paste_back_device(torch.sigmoid(self._forward(x)[:n, 0].float()), cb, sizes))
+                continue
             prob = torch.sigmoid(self._forward(x)[:n, 0].float()).cpu().numpy()       # one host read per batch
             for i in range(n):
                 full = helpers.crop2fullmask(prob[i], tuple(int(v) for v in cb[i]),
