@@ -14,7 +14,8 @@
 The reference has no such script (its network only runs inside `train_pascal.py`'s validation loop,
 `/root/reference/train_pascal.py:237-298`); checkpoints written by it load here as they do in training
 (utils.checkpoint.load_weights: ``module.`` prefixes, bare or wrapped state dicts, ``weights_only`` reads).
-Prints one JSON line: images, seconds, images/sec (decode and PNG writing excluded: ``forward_img_per_s``)."""
+Prints one JSON line: images, seconds, images/sec (``forward_img_per_s``: with ``--synthetic`` the second pass over
+the images in memory, PNG writing included unless ``--no-write``; with files the one pass, decode and writing included)."""
 from __future__ import annotations
 
 import argparse
@@ -141,7 +142,7 @@ def main(argv=None):
         n_files = len(files)
         if world > 1:            # this rank's share, dealt before anything is decoded: every world-th file
             files, points = files[rank::world], (points[rank::world] if points is not None else None)
-        images = [np.asarray(Image.open(f).convert("RGB"), dtype=np.uint8) for f in files]
+        images = None            # decoded a group at a time (below): a directory need not fit into memory
         names = [os.path.splitext(os.path.basename(f))[0] for f in files]
 
     if args.synthetic:
@@ -152,29 +153,13 @@ def main(argv=None):
     else:
         n_total = n_files
 
-    def run():
-        if not images:
-            return []
-        if instance:
-            return pred.predict(images, points)
-        return pred.predict(images)
+    pal = voc_palette().reshape(-1).tolist()
 
-    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
-    t0 = time.perf_counter()
-    results = run()              # first pass: tile choices, graph captures
-    sync()
-    t_first = time.perf_counter() - t0
-    t_steady = None
-    if args.synthetic:           # a second pass over the same images is the steady rate
-        t0 = time.perf_counter()
-        results = run()
-        sync()
-        t_steady = time.perf_counter() - t0
-
-    if not args.no_write:
+    def write(nms, results):
+        if args.no_write:
+            return
         os.makedirs(args.output, exist_ok=True)
-        pal = voc_palette().reshape(-1).tolist()
-        for nm, r in zip(names, results):
+        for nm, r in zip(nms, results):
             if instance:
                 Image.fromarray(((r > args.threshold) * 255).astype(np.uint8), mode="L").save(
                     os.path.join(args.output, nm + ".png"))
@@ -182,6 +167,29 @@ def main(argv=None):
                 im = Image.fromarray(r, mode="P")
                 im.putpalette(pal)
                 im.save(os.path.join(args.output, nm + ".png"))
+
+    def run(emit=False):
+        """One pass over this rank's images in groups of 16 batches: decode (files), predict, write (``emit``)."""
+        group = max(16 * args.batch, 64)
+        for g0 in range(0, len(names), group):
+            sl = slice(g0, g0 + group)
+            imgs = images[sl] if images is not None else [np.asarray(Image.open(f).convert("RGB"), dtype=np.uint8)
+                                                          for f in files[sl]]
+            res = pred.predict(imgs, points[sl]) if instance else pred.predict(imgs)
+            if emit:
+                write(names[sl], res)
+
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
+    t0 = time.perf_counter()
+    run(emit=not args.synthetic)         # first pass: tile choices, graph captures (files: decode and PNG writing inside)
+    sync()
+    t_first = time.perf_counter() - t0
+    t_steady = None
+    if args.synthetic:           # a second pass over the same images is the steady rate
+        t0 = time.perf_counter()
+        run(emit=True)
+        sync()
+        t_steady = time.perf_counter() - t0
     if world > 1:
         # the job's rate: all images over the slowest rank's time
         t_first = dist_env.all_reduce_scalar(t_first, "max", device if device.type == "cuda" else None)
